@@ -1,0 +1,207 @@
+"""Device-side plumbing: tensors in, C-ABI handles out.  torch is used for device memory, streams and
+events only; every arithmetic operation on the hot path is a HIP kernel behind include/fos.h."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.FosError("fastoptsolver_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                            "there is no CPU fallback by design")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def is_tensor(x):
+    return isinstance(x, torch.Tensor)
+
+
+def to_device_vec(x, device=None):
+    """1-D float32 contiguous CUDA tensor from ndarray / tensor."""
+    if is_tensor(x):
+        t = x.detach()
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    return t.to(device=dev, dtype=torch.float32).contiguous()
+
+
+def from_device_vec(t, like):
+    """Return `t` as the same kind of object the caller handed in (ndarray float64 / tensor)."""
+    if is_tensor(like):
+        return t.clone()
+    return t.detach().to("cpu", torch.float64).numpy()
+
+
+class Problem:
+    """A (m x n, fp32 or bf16, row-major) and b bound to a fos_problem handle.
+
+    Accepts ndarrays or tensors; a contiguous CUDA tensor of the right dtype is borrowed without a copy.
+    Build it once with ``prepare(A, b)`` and pass it wherever the solvers take ``A`` to avoid re-uploading A.
+    """
+
+    def __init__(self, A, b=None, dtype=None):
+        require_gpu()
+        lib = _lib.load()
+        self.like = A
+        want_bf16 = (dtype in ("bf16", torch.bfloat16)) or (dtype is None and is_tensor(A) and A.dtype == torch.bfloat16)
+        tdtype = torch.bfloat16 if want_bf16 else torch.float32
+        dev = A.device if is_tensor(A) and A.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        if is_tensor(A):
+            At = A.detach()
+        else:
+            At = torch.from_numpy(np.asarray(A))
+        if At.dim() != 2:
+            raise ValueError("A must be 2-D")
+        if not (At.is_cuda and At.dtype == tdtype and At.stride(1) == 1 and At.stride(0) >= At.shape[1]):
+            At = At.to(device=dev, dtype=tdtype).contiguous()
+        self.A = At
+        self.m, self.n = int(At.shape[0]), int(At.shape[1])
+        self.lda = int(At.stride(0)) if self.m > 1 else self.n
+        self.device = At.device
+        self.dtype = "bf16" if want_bf16 else "f32"
+        self.b = None if b is None else to_device_vec(b, self.device)
+        if self.b is not None and self.b.numel() != self.m:
+            raise ValueError("b must have m entries")
+        self.gbuf = torch.zeros(self.n + 4, dtype=torch.float32, device=self.device)
+        self.scratch = torch.zeros(16, dtype=torch.float64, device=self.device)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.fos_problem_create(C.byref(h), ptr(self.A), self.m, self.n, self.lda,
+                                              _lib.FOS_BF16 if want_bf16 else _lib.FOS_F32, ptr(self.b), stream_ptr()),
+                       "fos_problem_create")
+            self.h = h
+            _lib.check(lib.fos_problem_set_gbuf(self.h, ptr(self.gbuf)), "fos_problem_set_gbuf")
+        self.lib = lib
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h:
+            try:
+                self.lib.fos_problem_destroy(h)
+            except Exception:
+                pass
+            self.h = None
+
+    # ---- plan / tuning -------------------------------------------------------------------------------
+    def plan(self):
+        arr = (C.c_int32 * 8)()
+        _lib.check(self.lib.fos_problem_plan(self.h, arr), "fos_problem_plan")
+        keys = ("path", "threads", "chunks", "rows", "workgroups", "slabs", "nontemporal", "cus")
+        return dict(zip(keys, list(arr)))
+
+    def tune(self, threads, chunks, rows, workgroups=0):
+        _lib.check(self.lib.fos_problem_tune(self.h, threads, chunks, rows, workgroups), "fos_problem_tune")
+
+    # ---- kernels -------------------------------------------------------------------------------------
+    def gemv_pair(self, y, alpha2=0.0, out=None, rr_out=None):
+        """grad = A^T (A y - b) + alpha2 y (device tensor); rr_out: optional 1-element float64 device tensor."""
+        if out is None:
+            out = torch.empty(self.n, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fos_gemv_pair(self.h, ptr(y), float(alpha2), ptr(out), ptr(rr_out)), "fos_gemv_pair")
+        return out
+
+    def residual_objective(self, x):
+        """Host tuple (||Ax-b||^2, ||x||^2, ||x||_1); synchronises."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fos_residual_objective(self.h, ptr(x), ptr(self.scratch)), "fos_residual_objective")
+        v = self.scratch[:3].cpu()
+        return float(v[0]), float(v[1]), float(v[2])
+
+    def power_iter(self, v0, n_iter=100, tol=1e-6):
+        v = to_device_vec(v0, self.device).clone()
+        L = C.c_double()
+        it = C.c_int()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fos_power_iter(self.h, ptr(v), int(n_iter), float(tol), C.byref(L), C.byref(it)),
+                       "fos_power_iter")
+        return L.value, it.value, v
+
+
+def prepare(A, b=None, dtype=None):
+    """Upload/bind A (and b) once; the result can be passed as ``A`` to every solver (``b`` may then be None)."""
+    return A if isinstance(A, Problem) else Problem(A, b, dtype)
+
+
+def as_problem(A, b, dtype=None):
+    if isinstance(A, Problem):
+        if b is not None and A.b is None:
+            raise ValueError("Problem was prepared without b")
+        return A
+    return Problem(A, b, dtype)
+
+
+class Fista:
+    """fos_fista handle: x_k, x_{k-1} and the momentum scalars live on the device."""
+
+    def __init__(self, prob):
+        self.prob = prob
+        self.lib = prob.lib
+        h = C.c_void_p()
+        with torch.cuda.device(prob.device):
+            _lib.check(self.lib.fos_fista_create(prob.h, C.byref(h)), "fos_fista_create")
+        self.h = h
+        self.prm = _lib.FistaParams()
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h:
+            try:
+                self.lib.fos_fista_destroy(h)
+            except Exception:
+                pass
+            self.h = None
+
+    def reset(self, tau, alpha1, alpha2, mode=_lib.MODE_FISTA, prox_kind=_lib.PROX_L1, delta=0.0,
+              adaptive_restart=False, restart_threshold=1.0, tol_step=0.0, tol_ratio=0.0, x0=None):
+        p = self.prm
+        p.tau, p.alpha1, p.alpha2, p.delta = float(tau), float(alpha1), float(alpha2), float(delta)
+        p.restart_threshold, p.tol_step, p.tol_ratio = float(restart_threshold), float(tol_step), float(tol_ratio)
+        p.mode, p.prox_kind, p.adaptive_restart, p.reserved = int(mode), int(prox_kind), int(bool(adaptive_restart)), 0
+        with torch.cuda.device(self.prob.device):
+            _lib.check(self.lib.fos_fista_reset(self.h, C.byref(p), ptr(x0)), "fos_fista_reset")
+
+    def set_tau(self, tau):
+        _lib.check(self.lib.fos_fista_set_tau(self.h, float(tau)), "fos_fista_set_tau")
+
+    def run(self, iters):
+        with torch.cuda.device(self.prob.device):
+            _lib.check(self.lib.fos_fista_run(self.h, int(iters)), "fos_fista_run")
+
+    def grad(self):
+        with torch.cuda.device(self.prob.device):
+            _lib.check(self.lib.fos_fista_grad(self.h), "fos_fista_grad")
+
+    def update(self):
+        with torch.cuda.device(self.prob.device):
+            _lib.check(self.lib.fos_fista_update(self.h), "fos_fista_update")
+
+    def trial(self, t, with_residual=True):
+        out = (C.c_double * 6)()
+        with torch.cuda.device(self.prob.device):
+            _lib.check(self.lib.fos_fista_trial(self.h, float(t), int(bool(with_residual)), out), "fos_fista_trial")
+        return list(out)
+
+    def status(self):
+        st = _lib.FistaStatus()
+        with torch.cuda.device(self.prob.device):
+            _lib.check(self.lib.fos_fista_status_get(self.h, C.byref(st)), "fos_fista_status_get")
+        return st
+
+    def x_tensor(self):
+        """Copy of x_k as a device tensor."""
+        out = torch.empty(self.prob.n, dtype=torch.float32, device=self.prob.device)
+        with torch.cuda.device(self.prob.device):
+            _lib.check(self.lib.fos_fista_get_x(self.h, ptr(out)), "fos_fista_get_x")
+        return out

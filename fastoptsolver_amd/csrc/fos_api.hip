@@ -1,0 +1,573 @@
+// libfos_hip.so — C ABI (include/fos.h) over the gfx950 kernels.  Host code only decides launch geometry and
+// enqueues kernels; there is no CPU compute fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fos.h"
+#include "gemv_pair.hpp"
+#include "lbfgs_kernels.hpp"
+#include "reduce_update.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess)                                                                               \
+      return fail(FOS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+  } while (0)
+#define LAUNCH_CHECK()                                                                                  \
+  do {                                                                                                  \
+    hipError_t e_ = hipGetLastError();                                                                  \
+    if (e_ != hipSuccess) return fail(FOS_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e_)); \
+  } while (0)
+
+using fos::YSource;
+
+// ---- fused-kernel menu -------------------------------------------------------------------------------
+typedef void (*FusedLaunch)(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw,
+                            float* slabs, double* rr_part, int nwg, hipStream_t st);
+
+template <typename T, int THREADS, int K, int R, int MINW, bool WITH_G>
+void fused_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, float* slabs,
+                  double* rr_part, int nwg, hipStream_t st) {
+  hipLaunchKernelGGL((fos::gemv_pair_kernel<T, THREADS, K, R, true, MINW, WITH_G>), dim3(nwg), dim3(THREADS), 0, st,
+                     reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part);
+}
+
+struct MenuEntry {
+  int dtype, threads, k, r;
+  FusedLaunch with_g, resid_only;
+};
+#define ENTRY(DT, T, TH, K, R, W) \
+  { DT, TH, K, R, fused_launch<T, TH, K, R, W, true>, fused_launch<T, TH, K, R, W, false> }
+// Ordered by capacity (threads*k*EPC columns); first entry that fits n is the default.
+const MenuEntry kMenu[] = {
+    ENTRY(FOS_F32, float, 256, 1, 4, 2),   ENTRY(FOS_F32, float, 256, 2, 4, 2),  ENTRY(FOS_F32, float, 256, 4, 2, 2),
+    ENTRY(FOS_F32, float, 512, 4, 2, 2),   ENTRY(FOS_F32, float, 512, 8, 1, 2),  ENTRY(FOS_F32, float, 512, 8, 2, 2),
+    ENTRY(FOS_F32, float, 1024, 4, 1, 4),  ENTRY(FOS_F32, float, 1024, 2, 2, 4),
+    ENTRY(FOS_BF16, fos::bf16_t, 256, 1, 4, 2), ENTRY(FOS_BF16, fos::bf16_t, 256, 2, 2, 2),
+    ENTRY(FOS_BF16, fos::bf16_t, 256, 4, 2, 2), ENTRY(FOS_BF16, fos::bf16_t, 512, 4, 2, 2),
+    ENTRY(FOS_BF16, fos::bf16_t, 1024, 2, 2, 4),
+};
+
+const MenuEntry* find_entry(int dtype, int threads, int k, int r) {
+  for (const auto& e : kMenu)
+    if (e.dtype == dtype && e.threads == threads && e.k == k && e.r == r) return &e;
+  return nullptr;
+}
+int epc_of(int dtype) { return dtype == FOS_F32 ? 4 : 8; }
+const MenuEntry* default_entry(int dtype, int64_t n) {
+  for (const auto& e : kMenu)
+    if (e.dtype == dtype && (int64_t)e.threads * e.k * epc_of(dtype) >= n) return &e;
+  return nullptr;
+}
+
+int grid_1d(int64_t n, int per_block, int cap) {
+  int64_t g = (n + per_block - 1) / per_block;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
+}
+
+}  // namespace
+
+struct fos_problem {
+  const void* A = nullptr;
+  const float* b = nullptr;
+  int64_t m = 0, n = 0, lda = 0;
+  int dtype = FOS_F32;
+  hipStream_t stream = nullptr;
+  int ncu = 256;
+  // plan
+  int path = 0;                      // 0 fused, 1 two-pass fallback
+  const MenuEntry* entry = nullptr;
+  int nwg = 0;                       // workgroups of the fused kernel
+  int nslabs = 0;
+  int64_t rows_per_wg = 0;
+  int resid_grid = 0;                // fallback pass-1 grid
+  bool vec4 = false;                 // n % 4 == 0: float4 epilogues
+  // workspace
+  int slab_cap = 0, rr_cap = 0;
+  float* slabs = nullptr;
+  double* rr_part = nullptr;
+  float* rvec = nullptr;             // fallback: residual (m floats)
+  float* gbuf = nullptr;             // n + 4 floats (internal, or caller-owned after fos_problem_set_gbuf)
+  float* gbuf_own = nullptr;
+  float* ybuf = nullptr;             // n floats: aligned copy of a caller vector when needed
+  double* dscal = nullptr;           // 128 device doubles (scalars, power-iteration history)
+  double* part = nullptr;            // partial sums of the small kernels
+  int part_cap = 0;
+};
+
+struct fos_fista {
+  fos_problem* p = nullptr;
+  fos::FistaParams prm{};
+  float *x_cur = nullptr, *x_prev = nullptr, *x_tmp = nullptr;
+  fos::FistaScalars* scal = nullptr;
+  double* out5 = nullptr;            // device
+  int nupd = 0;                      // workgroups of the update kernel
+};
+
+namespace {
+
+void plan_fused(fos_problem* p, const MenuEntry* e, int nwg_hint) {
+  p->entry = e;
+  p->path = 0;
+  int64_t m = p->m;
+  int nwg = nwg_hint > 0 ? nwg_hint : p->ncu;
+  const int64_t min_rows = 2 * (int64_t)e->r;
+  if (m < (int64_t)nwg * min_rows) nwg = (int)std::max<int64_t>(1, m / min_rows);
+  p->rows_per_wg = (m + nwg - 1) / nwg;
+  p->nwg = (int)((m + p->rows_per_wg - 1) / p->rows_per_wg);
+  p->nslabs = p->nwg;
+}
+
+void plan_fallback(fos_problem* p) {
+  p->entry = nullptr;
+  p->path = 1;
+  int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(64, p->m / 64));
+  p->rows_per_wg = (p->m + chunks - 1) / chunks;
+  p->nslabs = (int)((p->m + p->rows_per_wg - 1) / p->rows_per_wg);
+  p->nwg = p->nslabs;
+  p->resid_grid = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (p->m + 3) / 4));
+}
+
+int ensure_workspace(fos_problem* p) {
+  const int need_slabs = p->nslabs;
+  if (need_slabs > p->slab_cap) {
+    if (p->slabs) (void)hipFree(p->slabs);
+    HIP_TRY(hipMalloc(&p->slabs, (size_t)need_slabs * p->n * sizeof(float)));
+    p->slab_cap = need_slabs;
+  }
+  const int need_rr = std::max(p->nwg, std::max(p->resid_grid, 1));
+  if (need_rr > p->rr_cap) {
+    if (p->rr_part) (void)hipFree(p->rr_part);
+    HIP_TRY(hipMalloc(&p->rr_part, (size_t)need_rr * sizeof(double)));
+    p->rr_cap = need_rr;
+  }
+  if (p->path == 1 && p->rvec == nullptr) HIP_TRY(hipMalloc(&p->rvec, (size_t)p->m * sizeof(float)));
+  return FOS_OK;
+}
+
+// Enqueue the A pass for `ys`.  with_g: also produce the slabs (A^T r).  Returns number of rr partials.
+int launch_pass(fos_problem* p, const YSource& ys, const float* b, bool with_g, int* n_rr) {
+  if (p->path == 0) {
+    FusedLaunch fn = with_g ? p->entry->with_g : p->entry->resid_only;
+    fn(p->A, p->lda, b, p->m, (int)p->n, ys, p->rows_per_wg, p->slabs, p->rr_part, p->nwg, p->stream);
+    LAUNCH_CHECK();
+    *n_rr = p->nwg;
+    return FOS_OK;
+  }
+  if (p->dtype == FOS_F32)
+    hipLaunchKernelGGL(fos::residual_rows_kernel<float>, dim3(p->resid_grid), dim3(256), 0, p->stream,
+                       (const float*)p->A, p->lda, b, p->m, (int)p->n, ys, p->rvec, p->rr_part);
+  else
+    hipLaunchKernelGGL(fos::residual_rows_kernel<fos::bf16_t>, dim3(p->resid_grid), dim3(256), 0, p->stream,
+                       (const fos::bf16_t*)p->A, p->lda, b, p->m, (int)p->n, ys, p->rvec, p->rr_part);
+  LAUNCH_CHECK();
+  *n_rr = p->resid_grid;
+  if (with_g) {
+    dim3 grid((unsigned)((p->n + 255) / 256), (unsigned)p->nslabs);
+    if (p->dtype == FOS_F32)
+      hipLaunchKernelGGL(fos::transpose_rows_kernel<float>, grid, dim3(256), 0, p->stream, (const float*)p->A, p->lda,
+                         p->m, (int)p->n, p->rvec, ys.stopped, p->rows_per_wg, p->slabs);
+    else
+      hipLaunchKernelGGL(fos::transpose_rows_kernel<fos::bf16_t>, grid, dim3(256), 0, p->stream,
+                         (const fos::bf16_t*)p->A, p->lda, p->m, (int)p->n, p->rvec, ys.stopped, p->rows_per_wg,
+                         p->slabs);
+    LAUNCH_CHECK();
+  }
+  return FOS_OK;
+}
+
+int launch_slab_reduce(fos_problem* p, int n_rr, float* gbuf, double* rr_out, const int* stopped) {
+  const int grid = (int)((p->n + fos::RCOLS - 1) / fos::RCOLS);
+  if (p->vec4)
+    hipLaunchKernelGGL(fos::slab_reduce_kernel<true>, dim3(grid), dim3(256), 0, p->stream, p->slabs, p->nslabs,
+                       (int)p->n, p->rr_part, n_rr, gbuf, rr_out, stopped);
+  else
+    hipLaunchKernelGGL(fos::slab_reduce_kernel<false>, dim3(grid), dim3(256), 0, p->stream, p->slabs, p->nslabs,
+                       (int)p->n, p->rr_part, n_rr, gbuf, rr_out, stopped);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
+// A caller vector the fused prologue can read with 16-byte loads.
+int aligned_vec(fos_problem* p, const float* v, const float** out) {
+  if ((reinterpret_cast<uintptr_t>(v) & 15u) == 0) {
+    *out = v;
+    return FOS_OK;
+  }
+  HIP_TRY(hipMemcpyAsync(p->ybuf, v, (size_t)p->n * sizeof(float), hipMemcpyDeviceToDevice, p->stream));
+  *out = p->ybuf;
+  return FOS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fos_last_error(void) { return g_err.c_str(); }
+int fos_abi_version(void) { return FOS_ABI_VERSION; }
+
+int fos_problem_create(fos_problem** out, const void* A, int64_t m, int64_t n, int64_t lda, int a_dtype,
+                       const float* b, void* stream) {
+  if (!out || !A || m <= 0 || n <= 0 || lda < n) return fail(FOS_ERR_ARG, "fos_problem_create: bad shape/pointer");
+  if (a_dtype != FOS_F32 && a_dtype != FOS_BF16) return fail(FOS_ERR_ARG, "fos_problem_create: bad a_dtype");
+  if (n > (int64_t)1 << 30) return fail(FOS_ERR_ARG, "fos_problem_create: n too large");
+  fos_problem* p = new fos_problem();
+  p->A = A; p->b = b; p->m = m; p->n = n; p->lda = lda; p->dtype = a_dtype;
+  p->stream = reinterpret_cast<hipStream_t>(stream);
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    delete p;
+    return fail(FOS_ERR_HIP, "fos_problem_create: no HIP device");
+  }
+  p->ncu = prop.multiProcessorCount;
+  p->vec4 = (n % 4 == 0);
+  const int epc = epc_of(a_dtype);
+  const bool vec_ok = (n % epc == 0) && (lda % epc == 0) && ((reinterpret_cast<uintptr_t>(A) & 15u) == 0);
+  const MenuEntry* e = vec_ok ? default_entry(a_dtype, n) : nullptr;
+  if (e) plan_fused(p, e, 0); else plan_fallback(p);
+  int rc = ensure_workspace(p);
+  if (rc == FOS_OK) {
+    hipError_t he = hipMalloc(&p->gbuf_own, (size_t)(n + 4) * sizeof(float));
+    p->gbuf = p->gbuf_own;
+    if (he == hipSuccess) he = hipMalloc(&p->ybuf, (size_t)n * sizeof(float));
+    if (he == hipSuccess) he = hipMalloc(&p->dscal, 256 * sizeof(double));
+    p->part_cap = std::max(1024, (int)((n + fos::RCOLS - 1) / fos::RCOLS)) * 4;
+    if (he == hipSuccess) he = hipMalloc(&p->part, (size_t)p->part_cap * sizeof(double));
+    if (he != hipSuccess) rc = fail(FOS_ERR_HIP, std::string("fos_problem_create: ") + hipGetErrorString(he));
+  }
+  if (rc != FOS_OK) {
+    fos_problem_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return FOS_OK;
+}
+
+int fos_problem_destroy(fos_problem* p) {
+  if (!p) return FOS_OK;
+  void* bufs[] = {p->slabs, p->rr_part, p->rvec, p->gbuf_own, p->ybuf, p->dscal, p->part};
+  for (void* q : bufs)
+    if (q) (void)hipFree(q);
+  delete p;
+  return FOS_OK;
+}
+
+int fos_problem_plan(const fos_problem* p, int32_t plan[8]) {
+  if (!p || !plan) return fail(FOS_ERR_ARG, "fos_problem_plan: null");
+  plan[0] = p->path;
+  plan[1] = p->entry ? p->entry->threads : 256;
+  plan[2] = p->entry ? p->entry->k : 0;
+  plan[3] = p->entry ? p->entry->r : 0;
+  plan[4] = p->nwg;
+  plan[5] = p->nslabs;
+  plan[6] = p->path == 0 ? 1 : 0;
+  plan[7] = p->ncu;
+  return FOS_OK;
+}
+
+int fos_problem_tune(fos_problem* p, int threads, int chunks, int rows, int workgroups) {
+  if (!p) return fail(FOS_ERR_ARG, "fos_problem_tune: null");
+  if (p->path != 0) return fail(FOS_ERR_UNSUPPORTED, "fos_problem_tune: problem runs the two-pass fallback");
+  const MenuEntry* e = find_entry(p->dtype, threads, chunks, rows);
+  if (!e || (int64_t)e->threads * e->k * epc_of(p->dtype) < p->n)
+    return fail(FOS_ERR_UNSUPPORTED, "fos_problem_tune: geometry not instantiated or too narrow for n");
+  plan_fused(p, e, workgroups);
+  return ensure_workspace(p);
+}
+
+int fos_problem_set_gbuf(fos_problem* p, float* gbuf) {
+  if (!p) return fail(FOS_ERR_ARG, "fos_problem_set_gbuf: null");
+  if (gbuf && (reinterpret_cast<uintptr_t>(gbuf) & 15u)) return fail(FOS_ERR_ARG, "fos_problem_set_gbuf: misaligned");
+  p->gbuf = gbuf ? gbuf : p->gbuf_own;
+  return FOS_OK;
+}
+
+int fos_gemv_pair(fos_problem* p, const float* y, float alpha2, float* grad, double* rr_out) {
+  if (!p || !y || !grad) return fail(FOS_ERR_ARG, "fos_gemv_pair: null");
+  const float* ya = nullptr;
+  int rc = aligned_vec(p, y, &ya);
+  if (rc) return rc;
+  YSource ys{ya, nullptr, nullptr, nullptr, nullptr};
+  int n_rr = 0;
+  if ((rc = launch_pass(p, ys, p->b, true, &n_rr))) return rc;
+  if ((rc = launch_slab_reduce(p, n_rr, p->gbuf, rr_out, nullptr))) return rc;
+  hipLaunchKernelGGL(fos::add_l2_kernel, dim3(grid_1d(p->n, 256, 1024)), dim3(256), 0, p->stream, p->gbuf, alpha2, ya,
+                     grad, p->n);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
+int fos_residual_objective(fos_problem* p, const float* x, double* out3) {
+  if (!p || !x || !out3) return fail(FOS_ERR_ARG, "fos_residual_objective: null");
+  const float* xa = nullptr;
+  int rc = aligned_vec(p, x, &xa);
+  if (rc) return rc;
+  YSource ys{xa, nullptr, nullptr, nullptr, nullptr};
+  int n_rr = 0;
+  if ((rc = launch_pass(p, ys, p->b, false, &n_rr))) return rc;
+  hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(64), 0, p->stream, p->rr_part, n_rr, 1, out3);
+  hipLaunchKernelGGL(fos::vec_norms_kernel, dim3(1), dim3(fos::LB_THREADS), 0, p->stream, xa, p->n, out3 + 1);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
+int fos_power_iter(fos_problem* p, float* v_inout, int n_iter, double tol, double* L_out, int* iters_out) {
+  if (!p || !v_inout || !L_out || n_iter <= 0 || n_iter > 200)
+    return fail(FOS_ERR_ARG, "fos_power_iter: bad argument (n_iter must be 1..200)");
+  double* Lh = p->dscal + 32;   // n_iter + 1 slots
+  float* v = p->ybuf;
+  // v = v0 / ||v0||   (iterative_solvers.py:51)
+  hipLaunchKernelGGL(fos::power_normalize_kernel, dim3(1), dim3(1024), 0, p->stream, v_inout, (int)p->n, v, Lh + n_iter);
+  LAUNCH_CHECK();
+  for (int it = 0; it < n_iter; ++it) {
+    YSource ys{v, nullptr, nullptr, nullptr, nullptr};
+    int n_rr = 0, rc;
+    if ((rc = launch_pass(p, ys, nullptr, true, &n_rr))) return rc;                       // w = A^T (A v)   :54
+    if ((rc = launch_slab_reduce(p, n_rr, p->gbuf, nullptr, nullptr))) return rc;
+    hipLaunchKernelGGL(fos::power_normalize_kernel, dim3(1), dim3(1024), 0, p->stream, p->gbuf, (int)p->n, v,
+                       Lh + it);                                                         // L = ||w||, v = w/L :55-56
+    LAUNCH_CHECK();
+  }
+  std::vector<double> hL(n_iter);
+  HIP_TRY(hipMemcpyAsync(hL.data(), Lh, (size_t)n_iter * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipMemcpyAsync(v_inout, v, (size_t)p->n * sizeof(float), hipMemcpyDeviceToDevice, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  double prev = 0.0;
+  int used = n_iter;
+  for (int it = 0; it < n_iter; ++it) {           // |L - prev| < tol -> break   :57
+    if (std::fabs(hL[it] - prev) < tol) { used = it + 1; break; }
+    prev = hL[it];
+  }
+  *L_out = hL[used - 1];
+  if (iters_out) *iters_out = used;
+  return FOS_OK;
+}
+
+int fos_prox_l1(const float* v, float thr, float* out, int64_t n, void* stream) {
+  if (!v || !out || n < 0) return fail(FOS_ERR_ARG, "fos_prox_l1: bad argument");
+  if (n == 0) return FOS_OK;
+  hipLaunchKernelGGL(fos::prox_l1_kernel, dim3(grid_1d(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, v, thr, out, n);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
+int fos_prox_elastic_net(const float* v, float tau, float alpha1, float alpha2, float* out, int64_t n, void* stream) {
+  if (!v || !out || n < 0) return fail(FOS_ERR_ARG, "fos_prox_elastic_net: bad argument");
+  if (n == 0) return FOS_OK;
+  hipLaunchKernelGGL(fos::prox_enet_kernel, dim3(grid_1d(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, v, tau,
+                     alpha1, alpha2, out, n);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
+// ---- FISTA ---------------------------------------------------------------------------------------------
+int fos_fista_create(fos_problem* p, fos_fista** out) {
+  if (!p || !out) return fail(FOS_ERR_ARG, "fos_fista_create: null");
+  fos_fista* f = new fos_fista();
+  f->p = p;
+  const size_t nb = (size_t)p->n * sizeof(float);
+  hipError_t he = hipMalloc(&f->x_cur, nb);
+  if (he == hipSuccess) he = hipMalloc(&f->x_prev, nb);
+  if (he == hipSuccess) he = hipMalloc(&f->x_tmp, nb);
+  if (he == hipSuccess) he = hipMalloc(&f->scal, sizeof(fos::FistaScalars));
+  if (he == hipSuccess) he = hipMalloc(&f->out5, 8 * sizeof(double));
+  if (he != hipSuccess) {
+    fos_fista_destroy(f);
+    return fail(FOS_ERR_HIP, std::string("fos_fista_create: ") + hipGetErrorString(he));
+  }
+  f->nupd = (int)((p->n + fos::RCOLS - 1) / fos::RCOLS);
+  *out = f;
+  return FOS_OK;
+}
+
+int fos_fista_destroy(fos_fista* f) {
+  if (!f) return FOS_OK;
+  void* bufs[] = {f->x_cur, f->x_prev, f->x_tmp, f->scal, f->out5};
+  for (void* q : bufs)
+    if (q) (void)hipFree(q);
+  delete f;
+  return FOS_OK;
+}
+
+static void to_dev_params(const fos_fista_params* s, fos::FistaParams* d) {
+  d->alpha1 = (float)s->alpha1;
+  d->alpha2 = (float)s->alpha2;
+  d->tau = (float)s->tau;
+  d->mode = s->mode;
+  d->prox_kind = s->prox_kind;
+  d->delta = (float)s->delta;
+  d->adaptive_restart = s->adaptive_restart;
+  d->restart_threshold = (float)s->restart_threshold;
+  d->tol_step = s->tol_step;
+  d->tol_ratio = s->tol_ratio;
+}
+
+int fos_fista_reset(fos_fista* f, const fos_fista_params* prm, const float* x0) {
+  if (!f || !prm) return fail(FOS_ERR_ARG, "fos_fista_reset: null");
+  if (prm->mode < 0 || prm->mode > 2 || prm->prox_kind < 0 || prm->prox_kind > 1 || !(prm->tau > 0.0))
+    return fail(FOS_ERR_ARG, "fos_fista_reset: bad mode/prox_kind/tau");
+  to_dev_params(prm, &f->prm);
+  fos_problem* p = f->p;
+  const size_t nb = (size_t)p->n * sizeof(float);
+  if (x0) {
+    HIP_TRY(hipMemcpyAsync(f->x_cur, x0, nb, hipMemcpyDeviceToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(f->x_prev, x0, nb, hipMemcpyDeviceToDevice, p->stream));
+  } else {
+    HIP_TRY(hipMemsetAsync(f->x_cur, 0, nb, p->stream));
+    HIP_TRY(hipMemsetAsync(f->x_prev, 0, nb, p->stream));
+  }
+  fos::FistaScalars init{};
+  init.t_prev = 1.0;
+  init.ratio = INFINITY;
+  HIP_TRY(hipMemcpyAsync(f->scal, &init, sizeof(init), hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));   // `init` is a stack object
+  return FOS_OK;
+}
+
+int fos_fista_set_tau(fos_fista* f, double tau) {
+  if (!f || !(tau > 0.0)) return fail(FOS_ERR_ARG, "fos_fista_set_tau: bad argument");
+  f->prm.tau = (float)tau;
+  return FOS_OK;
+}
+
+static YSource fista_source(fos_fista* f) {
+  return YSource{nullptr, f->x_cur, f->x_prev, &f->scal->beta, &f->scal->stopped};
+}
+
+static int launch_finalize(fos_fista* f, int n_rr) {
+  fos_problem* p = f->p;
+  hipLaunchKernelGGL(fos::fista_finalize_kernel, dim3(1), dim3(64), 0, p->stream, p->part, f->nupd, p->rr_part, n_rr,
+                     f->scal, f->prm);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
+int fos_fista_run(fos_fista* f, int iters) {
+  if (!f || iters < 0) return fail(FOS_ERR_ARG, "fos_fista_run: bad argument");
+  fos_problem* p = f->p;
+  for (int it = 0; it < iters; ++it) {
+    int n_rr = 0, rc;
+    if ((rc = launch_pass(p, fista_source(f), p->b, true, &n_rr))) return rc;
+    if (p->vec4)
+      hipLaunchKernelGGL((fos::fista_update_kernel<true, true>), dim3(f->nupd), dim3(256), 0, p->stream, p->slabs,
+                         p->nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, (float*)nullptr, f->scal,
+                         f->prm, p->part);
+    else
+      hipLaunchKernelGGL((fos::fista_update_kernel<true, false>), dim3(f->nupd), dim3(256), 0, p->stream, p->slabs,
+                         p->nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, (float*)nullptr, f->scal,
+                         f->prm, p->part);
+    LAUNCH_CHECK();
+    if ((rc = launch_finalize(f, n_rr))) return rc;
+  }
+  return FOS_OK;
+}
+
+int fos_fista_grad(fos_fista* f) {
+  if (!f) return fail(FOS_ERR_ARG, "fos_fista_grad: null");
+  fos_problem* p = f->p;
+  int n_rr = 0, rc;
+  if ((rc = launch_pass(p, fista_source(f), p->b, true, &n_rr))) return rc;
+  return launch_slab_reduce(p, n_rr, p->gbuf, &f->scal->rr, &f->scal->stopped);
+}
+
+int fos_fista_update(fos_fista* f) {
+  if (!f) return fail(FOS_ERR_ARG, "fos_fista_update: null");
+  fos_problem* p = f->p;
+  if (p->vec4)
+    hipLaunchKernelGGL((fos::fista_update_kernel<false, true>), dim3(f->nupd), dim3(256), 0, p->stream,
+                       (const float*)nullptr, 0, p->gbuf, (int)p->n, f->x_cur, f->x_prev, (float*)nullptr, f->scal,
+                       f->prm, p->part);
+  else
+    hipLaunchKernelGGL((fos::fista_update_kernel<false, false>), dim3(f->nupd), dim3(256), 0, p->stream,
+                       (const float*)nullptr, 0, p->gbuf, (int)p->n, f->x_cur, f->x_prev, (float*)nullptr, f->scal,
+                       f->prm, p->part);
+  LAUNCH_CHECK();
+  return launch_finalize(f, 0);
+}
+
+int fos_fista_trial(fos_fista* f, double t, int with_residual, double out6[6]) {
+  if (!f || !out6 || !(t > 0.0)) return fail(FOS_ERR_ARG, "fos_fista_trial: bad argument");
+  fos_problem* p = f->p;
+  const int grid = grid_1d(p->n, 256, 256);
+  HIP_TRY(hipMemsetAsync(f->out5, 0, 8 * sizeof(double), p->stream));
+  hipLaunchKernelGGL(fos::fista_trial_kernel, dim3(grid), dim3(256), 0, p->stream, p->gbuf, (int)p->n, f->x_cur,
+                     f->x_prev, f->scal, f->prm, (float)t, f->x_tmp, (float*)nullptr, p->part);
+  hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(64), 0, p->stream, p->part, grid, 4, f->out5);
+  LAUNCH_CHECK();
+  // rr(y_k) was produced by fos_fista_grad; copy it before the trial pass reuses the partial buffer
+  HIP_TRY(hipMemcpyAsync(f->out5 + 5, &f->scal->rr, sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  if (with_residual) {
+    YSource ys{f->x_tmp, nullptr, nullptr, nullptr, nullptr};
+    int n_rr = 0, rc;
+    if ((rc = launch_pass(p, ys, p->b, false, &n_rr))) return rc;
+    hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(64), 0, p->stream, p->rr_part, n_rr, 1, f->out5 + 4);
+    LAUNCH_CHECK();
+  }
+  HIP_TRY(hipMemcpyAsync(out6, f->out5, 6 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return FOS_OK;
+}
+
+int fos_fista_status_get(fos_fista* f, fos_fista_status* out) {
+  if (!f || !out) return fail(FOS_ERR_ARG, "fos_fista_status_get: null");
+  fos::FistaScalars h;
+  HIP_TRY(hipMemcpyAsync(&h, f->scal, sizeof(h), hipMemcpyDeviceToHost, f->p->stream));
+  HIP_TRY(hipStreamSynchronize(f->p->stream));
+  out->t_prev = h.t_prev; out->beta = h.beta; out->this_step = h.this_step; out->prev_step = h.prev_step;
+  out->ratio = h.ratio; out->rr = h.rr; out->gnorm2 = h.gnorm2; out->xnorm1 = h.xnorm1; out->xnorm2 = h.xnorm2;
+  out->k = h.k; out->stopped = h.stopped; out->restarts = h.restarts;
+  return FOS_OK;
+}
+
+int fos_fista_get_x(fos_fista* f, float* dst) {
+  if (!f || !dst) return fail(FOS_ERR_ARG, "fos_fista_get_x: null");
+  HIP_TRY(hipMemcpyAsync(dst, f->x_cur, (size_t)f->p->n * sizeof(float), hipMemcpyDeviceToDevice, f->p->stream));
+  return FOS_OK;
+}
+float* fos_fista_x(fos_fista* f) { return f ? f->x_cur : nullptr; }
+float* fos_fista_gbuf(fos_fista* f) { return f ? f->p->gbuf : nullptr; }
+
+// ---- L-BFGS pieces ---------------------------------------------------------------------------------------
+int fos_lbfgs_two_loop(const float* g, const float* S, const float* Y, int hist, int head, int cap, int64_t n,
+                       float* d_out, void* stream) {
+  if (!g || !d_out || n <= 0 || hist < 0 || hist > fos::LB_MAXHIST || cap < hist || (hist > 0 && (!S || !Y)) ||
+      head < 0 || (cap > 0 && head >= cap))
+    return fail(FOS_ERR_ARG, "fos_lbfgs_two_loop: bad argument");
+  hipLaunchKernelGGL(fos::lbfgs_two_loop_kernel, dim3(1), dim3(fos::LB_THREADS), 0, (hipStream_t)stream, g, S, Y, hist,
+                     head, std::max(cap, 1), n, d_out);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
+int fos_vec_stats(const float* x, const float* g, const float* d, int64_t n, double* out4, void* stream) {
+  if (!out4 || n <= 0) return fail(FOS_ERR_ARG, "fos_vec_stats: bad argument");
+  hipLaunchKernelGGL(fos::vec_stats_kernel, dim3(1), dim3(fos::LB_THREADS), 0, (hipStream_t)stream, x, g, d, n, out4);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
+int fos_vec_axpby(double a, const float* x, double b, const float* y, float* out, int64_t n, void* stream) {
+  if (!x || !out || n <= 0 || (b != 0.0 && !y)) return fail(FOS_ERR_ARG, "fos_vec_axpby: bad argument");
+  hipLaunchKernelGGL(fos::vec_axpby_kernel, dim3(grid_1d(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, (float)a, x,
+                     (float)b, b != 0.0 ? y : nullptr, out, n);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,276 @@
+// Single-pass GEMV pair for gfx950:  slab[w] = sum_{rows i of workgroup w} A_i^T (A_i . y - b_i)
+//
+// Spec (not reference code; the reference is NumPy):  grad = A.T @ (A @ y - b)
+//   iterative_solvers.py:173 (fista), :292 (fista_delta), :54 (power iteration, b = 0), lbfgs.py:46-48 (fg).
+//
+// Design (HBM-bound, 1 flop/byte fp32): every A element is read from HBM exactly once.  A workgroup owns
+// whole rows.  Thread t owns the same columns in every row (16-byte chunks, chunk c of thread t starts at
+// column (c*THREADS + t) * EPC), so its slice of y and of the running gradient live in VGPRs for the whole
+// kernel.  Per step the workgroup takes R rows: partial dots per thread -> wave reduction -> one LDS exchange
+// between the waves -> r_i = A_i.y - b_i known to every thread -> g += A_i * r_i from the SAME registers.
+// The next R rows are already in flight (second register tile) while this happens.  Each workgroup finally
+// writes its n-float partial gradient ("slab"); a second tiny kernel (reduce_update.hpp) sums the slabs in
+// fixed order (deterministic, no float atomics) and applies prox + momentum.
+//
+// Why VALU and not MFMA for fp32 (DESIGN.md "MFMA analysis"): with one right-hand side a 16x16x4 f32 MFMA
+// retires 64 A elements per 32 cycles per SIMD = 16 B/clk/CU for the two products, v_fma_f32 retires them in
+// 4 cycles (256 B/clk/CU); the HBM stream needs ~13 B/clk/CU.  MFMA would run at ~80 % pipe utilisation just to
+// keep up and its 16x16 / 32x32 accumulator tile wastes 15/16 of the registers this design spends on in-flight rows.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fos {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Momentum scalars the FISTA prologue needs to rebuild y_k = x_k + beta (x_k - x_prev) in registers.
+struct YSource {
+  const float* y;        // explicit y (power iteration, L-BFGS, trial points) or nullptr
+  const float* x_cur;    // x_k
+  const float* x_prev;   // x_{k-1}
+  const double* beta;    // device scalar
+  const int* stopped;    // device flag: non-zero -> kernel is a no-op (solver already stopped)
+};
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+  static constexpr int EPC = 4;   // elements per 16-byte chunk
+  __device__ static inline void unpack(const u32x4& raw, float (&f)[4]) {
+    f[0] = __uint_as_float(raw.x); f[1] = __uint_as_float(raw.y);
+    f[2] = __uint_as_float(raw.z); f[3] = __uint_as_float(raw.w);
+  }
+};
+struct bf16_t { uint16_t bits; };
+template <> struct ElemTraits<bf16_t> {
+  static constexpr int EPC = 8;
+  __device__ static inline void unpack(const u32x4& raw, float (&f)[8]) {
+    // bf16 -> f32 is a 16-bit shift: exact.
+    f[0] = __uint_as_float(raw.x << 16); f[1] = __uint_as_float(raw.x & 0xffff0000u);
+    f[2] = __uint_as_float(raw.y << 16); f[3] = __uint_as_float(raw.y & 0xffff0000u);
+    f[4] = __uint_as_float(raw.z << 16); f[5] = __uint_as_float(raw.z & 0xffff0000u);
+    f[6] = __uint_as_float(raw.w << 16); f[7] = __uint_as_float(raw.w & 0xffff0000u);
+  }
+};
+
+template <bool NT>
+__device__ inline u32x4 load16(const void* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  else return *reinterpret_cast<const u32x4*>(p);
+}
+
+// Sum over the 64 lanes of a wave; every lane gets the total (butterfly, fixed order -> deterministic).
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// T: element type of A.  THREADS: workgroup size.  K: 16-byte chunks per thread per row.  R: rows per step.
+// Requirements (checked on the host): n % EPC == 0, lda % EPC == 0, A 16-byte aligned, n <= K*THREADS*EPC.
+// Rows of workgroup w: [w*rows_per_wg, min(m, (w+1)*rows_per_wg)).
+// WITH_G = false gives the residual-only pass (K5: ||A x - b||^2 for objectives / Armijo trials).
+template <typename T, int THREADS, int K, int R, bool NT, int MINW, bool WITH_G = true>
+__global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
+    const T* __restrict__ A, int64_t lda, const float* __restrict__ b, int64_t m, int n, YSource ys,
+    int64_t rows_per_wg, float* __restrict__ slabs, double* __restrict__ rr_part) {
+  using Tr = ElemTraits<T>;
+  constexpr int EPC = Tr::EPC;
+  constexpr int NW = THREADS / 64;
+  __shared__ float red[2][R][NW];
+
+  if (ys.stopped != nullptr && *ys.stopped != 0) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int64_t row_lo = (int64_t)blockIdx.x * rows_per_wg;
+  int64_t row_hi = row_lo + rows_per_wg;
+  if (row_hi > m) row_hi = m;
+
+  // ---- prologue: this thread's slice of y, straight into registers --------------------------------
+  float yv[K][EPC];
+  float gv[K][EPC];
+  bool live[K];
+  const float beta = (ys.y == nullptr) ? (float)(*ys.beta) : 0.f;
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+    const int col = (c * THREADS + tid) * EPC;
+    live[c] = col < n;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { yv[c][e] = 0.f; gv[c][e] = 0.f; }
+    if (live[c]) {
+#pragma unroll
+      for (int q = 0; q < EPC / 4; ++q) {
+        if (ys.y != nullptr) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(ys.y + col + 4 * q);
+          yv[c][4 * q + 0] = t.x; yv[c][4 * q + 1] = t.y; yv[c][4 * q + 2] = t.z; yv[c][4 * q + 3] = t.w;
+        } else {
+          const f32x4 xc = *reinterpret_cast<const f32x4*>(ys.x_cur + col + 4 * q);
+          const f32x4 xp = *reinterpret_cast<const f32x4*>(ys.x_prev + col + 4 * q);
+          // same expression as reduce_update.hpp::form_y -> bitwise identical y in both kernels
+          yv[c][4 * q + 0] = xc.x + beta * (xc.x - xp.x); yv[c][4 * q + 1] = xc.y + beta * (xc.y - xp.y);
+          yv[c][4 * q + 2] = xc.z + beta * (xc.z - xp.z); yv[c][4 * q + 3] = xc.w + beta * (xc.w - xp.w);
+        }
+      }
+    }
+  }
+
+  const int64_t nrows = row_hi - row_lo;           // may be <= 0 for trailing workgroups
+  const int64_t nsteps = nrows > 0 ? (nrows + R - 1) / R : 0;
+  const char* base = reinterpret_cast<const char*>(A) + (int64_t)tid * 16;
+  const int64_t row_bytes = lda * (int64_t)sizeof(T);
+  double rr = 0.0;
+
+  u32x4 tile[2][R][K];
+  auto issue = [&](int buf, int64_t step) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int64_t row = row_lo + step * R + r;
+      if (row >= row_hi) row = row_hi - 1;          // clamp: loaded but weighted by zero below
+      const char* rp = base + row * row_bytes;
+#pragma unroll
+      for (int c = 0; c < K; ++c) {
+        if (live[c]) tile[buf][r][c] = load16<NT>(rp + (int64_t)c * THREADS * 16);
+        else tile[buf][r][c] = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  };
+  auto consume = [&](int buf, int64_t step) {
+    float part[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+      for (int c = 0; c < K; ++c) {
+        float a[EPC];
+        Tr::unpack(tile[buf][r][c], a);
+#pragma unroll
+        for (int e = 0; e < EPC; e += 2) {
+          acc0 = fmaf(a[e], yv[c][e], acc0);
+          acc1 = fmaf(a[e + 1], yv[c][e + 1], acc1);
+        }
+      }
+      part[r] = wave_sum(acc0 + acc1);
+    }
+    const int pb = (int)(step & 1);
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) red[pb][r][wave] = part[r];
+    }
+    __syncthreads();
+    float res[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += red[pb][r][w];
+      const int64_t row = row_lo + step * R + r;
+      if (row < row_hi) {
+        if (b != nullptr) s -= b[row];
+        rr += (double)s * (double)s;
+      } else {
+        s = 0.f;
+      }
+      res[r] = s;
+    }
+    if constexpr (WITH_G) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+          float a[EPC];
+          Tr::unpack(tile[buf][r][c], a);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) gv[c][e] = fmaf(a[e], res[r], gv[c][e]);
+        }
+      }
+    }
+  };
+
+  if (nsteps > 0) issue(0, 0);
+  for (int64_t s = 0; s < nsteps; s += 2) {
+    if (s + 1 < nsteps) issue(1, s + 1);
+    consume(0, s);
+    if (s + 1 < nsteps) {
+      if (s + 2 < nsteps) issue(0, s + 2);
+      consume(1, s + 1);
+    }
+  }
+
+  // ---- epilogue: this workgroup's slab -------------------------------------------------------------
+  float* slab = slabs + (int64_t)blockIdx.x * n;
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+    if (WITH_G && live[c]) {
+      const int col = (c * THREADS + tid) * EPC;
+#pragma unroll
+      for (int q = 0; q < EPC / 4; ++q) {
+        f32x4 o = {gv[c][4 * q + 0], gv[c][4 * q + 1], gv[c][4 * q + 2], gv[c][4 * q + 3]};
+        *reinterpret_cast<f32x4*>(slab + col + 4 * q) = o;
+      }
+    }
+  }
+  if (tid == 0) rr_part[blockIdx.x] = rr;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Shape-generic two-pass fallback (any n, any lda, any alignment): correctness path for ragged problems
+// such as the 1000 x 5 Boston design (config 1).  Pass 1: one wave per row -> r.  Pass 2: thread per column.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T> __device__ inline float elem_to_float(T v);
+template <> __device__ inline float elem_to_float<float>(float v) { return v; }
+template <> __device__ inline float elem_to_float<bf16_t>(bf16_t v) { return __uint_as_float((unsigned)v.bits << 16); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void residual_rows_kernel(const T* __restrict__ A, int64_t lda,
+                                                           const float* __restrict__ b, int64_t m, int n,
+                                                           YSource ys, float* __restrict__ r_out,
+                                                           double* __restrict__ rr_part) {
+  if (ys.stopped != nullptr && *ys.stopped != 0) return;
+  __shared__ double wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float beta = (ys.y == nullptr) ? (float)(*ys.beta) : 0.f;
+  double rr = 0.0;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < m; row += (int64_t)gridDim.x * 4) {
+    const T* ar = A + row * lda;
+    float acc = 0.f;
+    for (int j = lane; j < n; j += 64) {
+      float yj;
+      if (ys.y != nullptr) yj = ys.y[j];
+      else { const float xc = ys.x_cur[j], xp = ys.x_prev[j]; yj = xc + beta * (xc - xp); }
+      acc = fmaf(elem_to_float<T>(ar[j]), yj, acc);
+    }
+    acc = wave_sum(acc);
+    if (b != nullptr) acc -= b[row];
+    if (lane == 0) r_out[row] = acc;
+    rr += (double)acc * (double)acc;
+  }
+  if (lane == 0) wsum[wave] = rr;
+  __syncthreads();
+  if (threadIdx.x == 0) rr_part[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// grid = (ceil(n/256), nchunks): block (cx, cy) sums rows of chunk cy for 256 columns -> slab[cy].
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_rows_kernel(const T* __restrict__ A, int64_t lda, int64_t m, int n,
+                                                            const float* __restrict__ r, const int* stopped,
+                                                            int64_t rows_per_chunk, float* __restrict__ slabs) {
+  if (stopped != nullptr && *stopped != 0) return;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int64_t lo = (int64_t)blockIdx.y * rows_per_chunk;
+  int64_t hi = lo + rows_per_chunk;
+  if (hi > m) hi = m;
+  if (j >= n) return;
+  float acc = 0.f;
+  for (int64_t row = lo; row < hi; ++row) acc = fmaf(elem_to_float<T>(A[row * lda + j]), r[row], acc);
+  slabs[(int64_t)blockIdx.y * n + j] = acc;
+}
+
+}  // namespace fos

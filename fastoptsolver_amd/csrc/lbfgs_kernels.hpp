@@ -1,0 +1,154 @@
+// L-BFGS device pieces: two-loop recursion in ONE launch + the small vector kernels of the line search.
+//
+// The reference has no L-BFGS arithmetic of its own: lbfgs.py:64 calls scipy.optimize.fmin_l_bfgs_b.
+// Spec restated in SURVEY.md 8(c) / oracle/fos_oracle.py::two_loop_direction:
+//   newest -> oldest:  rho_i = 1/(y_i.s_i), a_i = rho_i s_i.q, q -= a_i y_i
+//   q *= (s_last.y_last)/(y_last.y_last)
+//   oldest -> newest:  b = rho_i y_i.q, q += s_i (a_i - b);   d = -q
+//
+// n-vectors are tiny next to A (32-64 KiB): the kernel is launch-latency bound, so everything runs in one
+// 1024-thread workgroup with q kept in global/L2, coalesced float4 traffic and wave-level (shuffle)
+// reductions accumulated in fp64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gemv_pair.hpp"
+
+namespace fos {
+
+constexpr int LB_THREADS = 1024;
+constexpr int LB_MAXHIST = 64;
+
+// workgroup-wide sum of two doubles; result broadcast to every thread
+__device__ inline void block_sum2_bcast(double& a, double& b, double* lds /* 2*16 + 2 */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  a = wave_sum(a);
+  b = wave_sum(b);
+  __syncthreads();                       // previous readers of lds are done
+  if (lane == 0) { lds[wave] = a; lds[16 + wave] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sa = 0.0, sb = 0.0;
+    for (int i = 0; i < LB_THREADS / 64; ++i) { sa += lds[i]; sb += lds[16 + i]; }
+    lds[32] = sa; lds[33] = sb;
+  }
+  __syncthreads();
+  a = lds[32];
+  b = lds[33];
+}
+
+__global__ __launch_bounds__(LB_THREADS) void lbfgs_two_loop_kernel(const float* __restrict__ g,
+                                                                    const float* __restrict__ S,
+                                                                    const float* __restrict__ Y, int hist, int head,
+                                                                    int cap, int64_t n, float* __restrict__ q) {
+  __shared__ double lds[34];
+  __shared__ double coef[LB_MAXHIST];
+  __shared__ double rho[LB_MAXHIST];
+  const int tid = threadIdx.x;
+  for (int64_t i = tid; i < n; i += LB_THREADS) q[i] = g[i];
+  __syncthreads();
+  double sy_last = 1.0, yy_last = 1.0;
+  for (int h = hist - 1; h >= 0; --h) {
+    const int slot = (head + h) % cap;
+    const float* s = S + (int64_t)slot * n;
+    const float* y = Y + (int64_t)slot * n;
+    double sq = 0.0, ys = 0.0, yy = 0.0;
+    for (int64_t i = tid; i < n; i += LB_THREADS) {
+      const double sv = s[i], yv = y[i];
+      sq += sv * (double)q[i];
+      ys += yv * sv;
+      if (h == hist - 1) yy += yv * yv;
+    }
+    block_sum2_bcast(sq, ys, lds);
+    if (h == hist - 1) {
+      double dummy = 0.0;
+      block_sum2_bcast(yy, dummy, lds);
+      sy_last = ys;
+      yy_last = yy;
+    }
+    const double r = 1.0 / ys;
+    const double a = r * sq;
+    if (tid == 0) { coef[h] = a; rho[h] = r; }
+    for (int64_t i = tid; i < n; i += LB_THREADS) q[i] = (float)((double)q[i] - a * (double)y[i]);
+    __syncthreads();
+  }
+  if (hist > 0) {
+    const double gam = sy_last / yy_last;
+    for (int64_t i = tid; i < n; i += LB_THREADS) q[i] = (float)((double)q[i] * gam);
+    __syncthreads();
+  }
+  for (int h = 0; h < hist; ++h) {
+    const int slot = (head + h) % cap;
+    const float* s = S + (int64_t)slot * n;
+    const float* y = Y + (int64_t)slot * n;
+    double yq = 0.0, dummy = 0.0;
+    for (int64_t i = tid; i < n; i += LB_THREADS) yq += (double)y[i] * (double)q[i];
+    block_sum2_bcast(yq, dummy, lds);
+    const double w = coef[h] - rho[h] * yq;
+    for (int64_t i = tid; i < n; i += LB_THREADS) q[i] = (float)((double)q[i] + w * (double)s[i]);
+    __syncthreads();
+  }
+  for (int64_t i = tid; i < n; i += LB_THREADS) q[i] = -q[i];
+}
+
+// out4 = { x.x, g.d, d.d, max|g| }; any pointer may be NULL (its entries are then 0).
+__global__ __launch_bounds__(LB_THREADS) void vec_stats_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                               const float* __restrict__ d, int64_t n,
+                                                               double* __restrict__ out4) {
+  __shared__ double lds[4][16];
+  double xx = 0.0, gd = 0.0, dd = 0.0, gm = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += LB_THREADS) {
+    const double xv = x ? (double)x[i] : 0.0, gv = g ? (double)g[i] : 0.0, dv = d ? (double)d[i] : 0.0;
+    xx += xv * xv;
+    gd += gv * dv;
+    dd += dv * dv;
+    gm = fmax(gm, fabs(gv));
+  }
+  xx = wave_sum(xx); gd = wave_sum(gd); dd = wave_sum(dd);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) gm = fmax(gm, __shfl_xor(gm, off, 64));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { lds[0][wave] = xx; lds[1][wave] = gd; lds[2][wave] = dd; lds[3][wave] = gm; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0, c = 0.0, e = 0.0;
+    for (int i = 0; i < 16; ++i) { a += lds[0][i]; b += lds[1][i]; c += lds[2][i]; e = fmax(e, lds[3][i]); }
+    out4[0] = a; out4[1] = b; out4[2] = c; out4[3] = e;
+  }
+}
+
+// out3 = { ||x||^2, ||x||_1, 0 }
+__global__ __launch_bounds__(LB_THREADS) void vec_norms_kernel(const float* __restrict__ x, int64_t n,
+                                                               double* __restrict__ out2) {
+  __shared__ double lds[2][16];
+  double a = 0.0, b = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += LB_THREADS) { const double v = x[i]; a += v * v; b += fabs(v); }
+  a = wave_sum(a); b = wave_sum(b);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { lds[0][wave] = a; lds[1][wave] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sa = 0.0, sb = 0.0;
+    for (int i = 0; i < 16; ++i) { sa += lds[0][i]; sb += lds[1][i]; }
+    out2[0] = sa; out2[1] = sb;
+  }
+}
+
+__global__ __launch_bounds__(256) void vec_axpby_kernel(float a, const float* __restrict__ x, float b,
+                                                        const float* __restrict__ y, float* __restrict__ out,
+                                                        int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float v = a * x[i];
+    if (y != nullptr) v = fmaf(b, y[i], v);
+    out[i] = v;
+  }
+}
+
+// grad_out = gbuf + alpha2 * y   (L-BFGS fg: lbfgs.py:50-51)
+__global__ __launch_bounds__(256) void add_l2_kernel(const float* __restrict__ gbuf, float alpha2,
+                                                     const float* __restrict__ y, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = alpha2 != 0.f ? fmaf(alpha2, y[i], gbuf[i]) : gbuf[i];
+}
+
+}  // namespace fos

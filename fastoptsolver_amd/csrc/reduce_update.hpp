@@ -1,0 +1,355 @@
+// Slab reduction + prox / momentum epilogue + scalar finalisation for the FISTA family.
+//
+// Spec (reference is NumPy; these are new kernels):
+//   grad += alpha2 * y                     iterative_solvers.py:174-175, :293-294
+//   v = y - tau*grad ; x_next = prox_l1    iterative_solvers.py:200-201, :315-316 ; prox_operators.py:8, :15-16
+//   this_step / prev_step / ratio          iterative_solvers.py:204-206, :325-327
+//   momentum, adaptive restart             iterative_solvers.py:209-221 ; theta_k = k/(k+1+delta) :330-331
+//   stopping rules                         iterative_solvers.py:238, :242, :337, :341
+//
+// The slabs are summed in a fixed order (slab 0,1,2,... inside each group, groups 0..G-1): the result is
+// bit-reproducible run to run and identical on every rank of a sharded run after the all-reduce.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include "gemv_pair.hpp"
+
+namespace fos {
+
+enum : int { MODE_FISTA = 0, MODE_DELTA = 1, MODE_ISTA = 2 };
+enum : int { PROX_L1 = 0, PROX_ENET = 1 };   // PROX_ENET: l2 term inside the prox (prox_operators.py:10-16)
+enum : int { STOP_NONE = 0, STOP_STEP = 1, STOP_RATIO = 2, STOP_GRAD = 3 };
+
+// Loop-carried scalars that live on the device so that a run of iterations needs no host round trip.
+struct FistaScalars {
+  double t_prev;       // FISTA t_{k}
+  double beta;         // momentum used to rebuild y_k = x_k + beta (x_k - x_prev)
+  double this_step;    // ||x_k - x_{k-1}|| of the last completed iteration
+  double prev_step;    // the one before
+  double ratio;        // this/prev (inf when prev == 0)
+  double rr;           // ||A y - b||^2 of the last gradient
+  double gnorm2;       // ||grad||^2 of the last gradient (smooth part, incl. alpha2*y)
+  double xnorm1;       // ||x_k||_1   (filled by the update kernel: free by-products for the objective)
+  double xnorm2;       // ||x_k||_2^2
+  long long k;         // completed iterations
+  int stopped;         // STOP_*
+  int restarts;
+};
+
+struct FistaParams {
+  float alpha1;
+  float alpha2;        // smooth l2 weight (added to the gradient) when prox_kind == PROX_L1
+  float tau;           // step
+  int mode;            // MODE_*
+  int prox_kind;       // PROX_*
+  float delta;         // FISTA-delta parameter
+  int adaptive_restart;
+  float restart_threshold;
+  double tol_step;     // stop when this_step < tol_step   (0 = off)
+  double tol_ratio;    // stop when ratio < tol_ratio       (0 = off)
+};
+
+__device__ inline float form_y(float xc, float xp, float beta) { return xc + beta * (xc - xp); }
+
+__device__ inline float soft_threshold(float v, float thr) {
+  // sign(v) * max(|v| - thr, 0)  (prox_operators.py:8): NaN propagates, shrunk negatives give -0.0,
+  // np.sign(+-0) = +0 gives +0 whatever thr is.
+  float mag = fabsf(v) - thr;
+  mag = (mag < 0.0f) ? 0.0f : mag;
+  return v == 0.0f ? 0.0f : copysignf(mag, v);
+}
+
+// Block-wide sum of NV doubles per thread (256 threads); result valid in thread 0.
+template <int NV>
+__device__ inline void block_sum_256(double (&v)[NV], double* lds /* NV*4 doubles */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) lds[i * 4 + wave] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = (lds[i * 4 + 0] + lds[i * 4 + 1]) + (lds[i * 4 + 2] + lds[i * 4 + 3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Column-block reduction of the slabs.  Workgroup = 256 threads = QUADS float4 columns x GROUPS slab groups.
+// Returns (in the threads with grp == 0) the float4 sum for quad `q`; other threads get garbage.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int RQ = 16;             // float4 columns per workgroup  -> 64 columns
+constexpr int RG = 16;             // slab groups per workgroup
+constexpr int RCOLS = RQ * 4;
+
+__device__ inline f32x4 reduce_slab_block(const float* __restrict__ slabs, int nslabs, int n, int col0,
+                                          f32x4 (*lds)[RQ]) {
+  const int q = threadIdx.x % RQ, grp = threadIdx.x / RQ;
+  const int col = col0 + 4 * q;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (col < n) {
+    const float* p = slabs + col;
+    int s = grp;
+    for (; s + 3 * RG < nslabs; s += 4 * RG) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p + (int64_t)s * n);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(p + (int64_t)(s + RG) * n);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(p + (int64_t)(s + 2 * RG) * n);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(p + (int64_t)(s + 3 * RG) * n);
+      acc += a; acc += b; acc += c; acc += d;
+    }
+    for (; s < nslabs; s += RG) acc += *reinterpret_cast<const f32x4*>(p + (int64_t)s * n);
+  }
+  lds[grp][q] = acc;
+  __syncthreads();
+  f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+  if (grp == 0) {
+#pragma unroll
+    for (int g = 0; g < RG; ++g) tot += lds[g][q];
+  }
+  return tot;
+}
+
+// Scalar-tail variant for n % 4 != 0 (fallback path): one column per thread-quad element.
+__device__ inline float reduce_slab_scalar(const float* __restrict__ slabs, int nslabs, int n, int col) {
+  float acc = 0.f;
+  if (col < n)
+    for (int s = 0; s < nslabs; ++s) acc += slabs[(int64_t)s * n + col];
+  return acc;
+}
+
+// slabs -> gbuf[0..n) (+ sum of rr partials -> scal->rr and gbuf[n]).  grid = ceil(n / RCOLS).
+template <bool VEC>
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int nslabs, int n,
+                                                         const double* __restrict__ rr_part, int n_rr,
+                                                         float* __restrict__ gbuf, double* __restrict__ rr_out,
+                                                         const int* stopped) {
+  if (stopped != nullptr && *stopped != 0) return;
+  __shared__ f32x4 lds[RG][RQ];
+  const int col0 = blockIdx.x * RCOLS;
+  if constexpr (VEC) {
+    const f32x4 tot = reduce_slab_block(slabs, nslabs, n, col0, lds);
+    const int q = threadIdx.x % RQ, grp = threadIdx.x / RQ;
+    if (grp == 0 && col0 + 4 * q < n) *reinterpret_cast<f32x4*>(gbuf + col0 + 4 * q) = tot;
+  } else {
+    if (threadIdx.x < RCOLS) {
+      const int col = col0 + threadIdx.x;
+      const float v = reduce_slab_scalar(slabs, nslabs, n, col);
+      if (col < n) gbuf[col] = v;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {      // one wave folds the rr partials (fixed order)
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n_rr; i += 64) s += rr_part[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) {
+      if (rr_out != nullptr) *rr_out = s;
+      gbuf[n] = (float)s;     // rides along with the gradient in the multi-GPU all-reduce
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// FISTA update for RCOLS columns per workgroup.  FROM_SLABS: sum the slabs first (single-GPU fused path);
+// otherwise take the (all-reduced) gradient from gbuf.  Writes x_prev <- x_k, x_k <- x_next in place and
+// per-workgroup partial sums  part[wg] = {sum d^2, sum g_full^2, sum |x_next|, sum x_next^2}.
+// ---------------------------------------------------------------------------------------------------------
+template <bool FROM_SLABS, bool VEC>
+__global__ __launch_bounds__(256) void fista_update_kernel(const float* __restrict__ slabs, int nslabs,
+                                                          const float* __restrict__ gbuf, int n,
+                                                          float* __restrict__ x_cur, float* __restrict__ x_prev,
+                                                          float* __restrict__ g_full_out,
+                                                          const FistaScalars* __restrict__ scal, FistaParams prm,
+                                                          double* __restrict__ part) {
+  if (scal->stopped != 0) return;
+  __shared__ f32x4 lds[RG][RQ];
+  __shared__ double dl[4 * 4];
+  const int col0 = blockIdx.x * RCOLS;
+  const float beta = (float)scal->beta;
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  int col, cnt = 0;
+  bool owner;
+  if constexpr (VEC) {
+    const int q = threadIdx.x % RQ, grp = threadIdx.x / RQ;
+    col = col0 + 4 * q;
+    owner = (grp == 0) && (col < n);
+    if constexpr (FROM_SLABS) {
+      const f32x4 tot = reduce_slab_block(slabs, nslabs, n, col0, lds);
+      g[0] = tot.x; g[1] = tot.y; g[2] = tot.z; g[3] = tot.w;
+    } else if (owner) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(gbuf + col);
+      g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w;
+    }
+    cnt = owner ? 4 : 0;
+  } else {
+    col = col0 + threadIdx.x;
+    owner = (threadIdx.x < RCOLS) && (col < n);
+    if (owner) g[0] = FROM_SLABS ? reduce_slab_scalar(slabs, nslabs, n, col) : gbuf[col];
+    cnt = owner ? 1 : 0;
+  }
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  const float thr = prm.tau * prm.alpha1;
+  const float shrink = 1.0f / (1.0f + prm.tau * prm.alpha2);
+  for (int e = 0; e < cnt; ++e) {
+    const float xc = x_cur[col + e], xp = x_prev[col + e];
+    const float y = form_y(xc, xp, beta);
+    float gf = g[e];
+    if (prm.prox_kind == PROX_L1 && prm.alpha2 > 0.f) gf = fmaf(prm.alpha2, y, gf);
+    const float v = y - prm.tau * gf;
+    float xn = prm.alpha1 > 0.f ? soft_threshold(v, thr) : v;
+    if (prm.prox_kind == PROX_ENET) xn = (prm.alpha1 > 0.f ? xn : v) * shrink;
+    const float d = xn - xc;
+    acc[0] += (double)d * (double)d;
+    acc[1] += (double)gf * (double)gf;
+    acc[2] += fabs((double)xn);
+    acc[3] += (double)xn * (double)xn;
+    x_prev[col + e] = xc;
+    x_cur[col + e] = xn;
+    if (g_full_out != nullptr) g_full_out[col + e] = gf;
+  }
+  block_sum_256<4>(acc, dl);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x * 4 + 0] = acc[0]; part[blockIdx.x * 4 + 1] = acc[1];
+    part[blockIdx.x * 4 + 2] = acc[2]; part[blockIdx.x * 4 + 3] = acc[3];
+  }
+}
+
+// One wave: fold the partials and advance the scalar state.  iterative_solvers.py:204-221, :235-242, :325-342.
+__global__ __launch_bounds__(64) void fista_finalize_kernel(const double* __restrict__ part, int nparts,
+                                                           const double* __restrict__ rr_part, int n_rr,
+                                                           FistaScalars* __restrict__ scal, FistaParams prm) {
+  if (scal->stopped != 0) return;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < nparts; i += 64) {
+    s[0] += part[i * 4 + 0]; s[1] += part[i * 4 + 1]; s[2] += part[i * 4 + 2]; s[3] += part[i * 4 + 3];
+  }
+  double rr = 0.0;
+  for (int i = threadIdx.x; i < n_rr; i += 64) rr += rr_part[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s[i] = wave_sum(s[i]);
+  rr = wave_sum(rr);
+  if (threadIdx.x != 0) return;
+  const double step = sqrt(s[0]);
+  const double prev = scal->this_step;
+  const double ratio = prev > 0.0 ? step / prev : INFINITY;
+  double beta = 0.0;
+  if (prm.mode == MODE_FISTA) {
+    const double t = scal->t_prev;
+    double t_new;
+    if (prm.adaptive_restart && ratio > (double)prm.restart_threshold) {
+      t_new = 1.0;
+      beta = 0.0;
+      scal->restarts += 1;
+    } else {
+      t_new = 0.5 * (1.0 + sqrt(1.0 + 4.0 * t * t));
+      beta = (t - 1.0) / t_new;
+    }
+    scal->t_prev = t_new;
+  } else if (prm.mode == MODE_DELTA) {
+    const double kk = (double)(scal->k + 1);
+    beta = kk / (kk + 1.0 + (double)prm.delta);
+  }
+  scal->beta = beta;
+  scal->prev_step = prev;
+  scal->this_step = step;
+  scal->ratio = ratio;
+  scal->gnorm2 = s[1];
+  scal->xnorm1 = s[2];
+  scal->xnorm2 = s[3];
+  if (n_rr > 0) scal->rr = rr;
+  scal->k += 1;
+  int stop = STOP_NONE;
+  if (prm.tol_step > 0.0 && step < prm.tol_step) stop = STOP_STEP;
+  if (stop == STOP_NONE && prm.tol_ratio > 0.0 && ratio < prm.tol_ratio) stop = STOP_RATIO;
+  scal->stopped = stop;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Backtracking trial (iterative_solvers.py:187-191): x_tmp = prox(y - t*g_full), and the three scalars the
+// Armijo test needs besides g(x_tmp):  out = {g_full . (x_tmp - y), ||x_tmp||^2, ||y||^2, ||g_full||^2}.
+// Single workgroup per RCOLS*4 columns; partials folded by trial_finalize.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fista_trial_kernel(const float* __restrict__ gbuf, int n,
+                                                         const float* __restrict__ x_cur,
+                                                         const float* __restrict__ x_prev,
+                                                         const FistaScalars* __restrict__ scal, FistaParams prm,
+                                                         float t_trial, float* __restrict__ x_tmp,
+                                                         float* __restrict__ y_out, double* __restrict__ part) {
+  __shared__ double dl[4 * 4];
+  const float beta = (float)scal->beta;
+  const float thr = t_trial * prm.alpha1;
+  const float shrink = 1.0f / (1.0f + t_trial * prm.alpha2);
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int col = blockIdx.x * 256 + threadIdx.x; col < n; col += gridDim.x * 256) {
+    const float y = form_y(x_cur[col], x_prev[col], beta);
+    float gf = gbuf[col];
+    if (prm.prox_kind == PROX_L1 && prm.alpha2 > 0.f) gf = fmaf(prm.alpha2, y, gf);
+    const float v = y - t_trial * gf;
+    float xt = prm.alpha1 > 0.f ? soft_threshold(v, thr) : v;
+    if (prm.prox_kind == PROX_ENET) xt = (prm.alpha1 > 0.f ? xt : v) * shrink;
+    x_tmp[col] = xt;
+    if (y_out != nullptr) y_out[col] = y;
+    acc[0] += (double)gf * ((double)xt - (double)y);
+    acc[1] += (double)xt * (double)xt;
+    acc[2] += (double)y * (double)y;
+    acc[3] += (double)gf * (double)gf;
+  }
+  block_sum_256<4>(acc, dl);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) part[blockIdx.x * 4 + i] = acc[i];
+  }
+}
+
+// Fold `nparts` rows of `width` doubles (fixed order) into out[width].  One wave.
+__global__ __launch_bounds__(64) void fold_partials_kernel(const double* __restrict__ part, int nparts, int width,
+                                                          double* __restrict__ out) {
+  for (int w = 0; w < width; ++w) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) s += part[i * width + w];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[w] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Stand-alone prox kernels (prox_operators.py:3-8, :10-16) for the ista() callable path.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prox_l1_kernel(const float* __restrict__ v, float thr, float* __restrict__ out,
+                                                     int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = soft_threshold(v[i], thr);
+}
+__global__ __launch_bounds__(256) void prox_enet_kernel(const float* __restrict__ v, float tau, float a1, float a2,
+                                                       float* __restrict__ out, int64_t n) {
+  const float thr = tau * a1, inv = 1.0f + tau * a2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = soft_threshold(v[i], thr) / inv;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Power iteration tail (iterative_solvers.py:55-56): L = ||w||, v = w / L.  One workgroup.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void power_normalize_kernel(const float* __restrict__ w, int n,
+                                                              float* __restrict__ v, double* __restrict__ L_out) {
+  __shared__ double ws[16];
+  __shared__ double Ls;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) acc += (double)w[i] * (double)w[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < 16; ++i) s += ws[i];
+    Ls = sqrt(s);
+    *L_out = Ls;
+  }
+  __syncthreads();
+  const double L = Ls;
+  for (int i = threadIdx.x; i < n; i += 1024) v[i] = (float)((double)w[i] / L);
+}
+
+}  // namespace fos

@@ -1,0 +1,318 @@
+"""MI355X drop-in for the reference's ``iterative_solvers.py``: same names, positional order, defaults,
+return shapes, history keys, metric keys, exceptions and RNG consumption — the loop bodies are HIP kernels.
+
+Reference lines cited as ``ref:LINE`` are ``iterative_solvers.py:LINE`` of ElBaldo1/FastOptSolver.
+
+Extensions are keyword-only: ``L=`` (skip the power iteration), ``dtype="bf16"`` (store A in bf16,
+accumulate in fp32), ``check_every=`` (how often the host polls the device stop flag).
+``A`` may be an ndarray, a tensor or a ``prepare(A, b)`` handle; results come back as the kind that went in
+(ndarray float64 / tensor float32).
+"""
+from __future__ import annotations
+
+import math
+import time
+
+import numpy as np
+import torch
+
+from . import _core, _lib
+from .operators import ElasticNetProx, L1Prox, LeastSquares
+
+# ref:11 — Armijo sufficient-decrease constant, read at call time (callers may monkey-patch it)
+C: float = 1e-2
+
+# ref:16-18 — module-level metric lists (seconds; device time where a kernel is what was timed)
+grad_call_times = []
+ls_call_times = []
+ls_call_iters = []
+
+
+def reset_metrics() -> None:
+    """ref:20-24"""
+    grad_call_times.clear()
+    ls_call_times.clear()
+    ls_call_iters.clear()
+
+
+def get_metrics():
+    """ref:26-40 — the same seven keys.  With the fused step, "gradient time" is the device time of the
+    gradient kernels (host-driven mode) or the per-iteration share of the fused run (device-driven mode)."""
+    return {
+        'grad_num_calls':   len(grad_call_times),
+        'grad_time_total':  sum(grad_call_times),
+        'grad_time_mean':   np.mean(grad_call_times) if grad_call_times else 0.0,
+        'ls_num_calls':     len(ls_call_times),
+        'ls_time_total':    sum(ls_call_times),
+        'ls_time_mean':     np.mean(ls_call_times) if ls_call_times else 0.0,
+        'ls_iters_total':   sum(ls_call_iters),
+    }
+
+
+class _EventTimer:
+    """Pairs of device events on the current stream; resolved to seconds at flush()."""
+
+    def __init__(self, sink):
+        self.sink = sink
+        self.pending = []
+
+    def start(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def stop(self, ev0, count=1):
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        self.pending.append((ev0, ev1, count))
+
+    def flush(self):
+        if not self.pending:
+            return
+        self.pending[-1][1].synchronize()
+        for ev0, ev1, count in self.pending:
+            dt = ev0.elapsed_time(ev1) * 1e-3 / count
+            self.sink.extend([dt] * count)
+        self.pending.clear()
+
+
+# ---------------------------------------------------------------------
+# Estimate Lipschitz constant L = λ_max(AᵀA)                    ref:45-60
+# ---------------------------------------------------------------------
+def estimate_lipschitz(A, n_iter: int = 100, tol: float = 1e-6) -> float:
+    """Power iteration on the device (w = Aᵀ(Av) is the single-pass GEMV-pair kernel with b = 0).
+    Draws ``np.random.randn(n)`` from the global legacy stream exactly like ref:50."""
+    prob = _core.prepare(A)
+    v0 = np.random.randn(prob.n)
+    L, _, _ = prob.power_iter(v0, n_iter=n_iter, tol=tol)
+    return L
+
+
+# ---------------------------------------------------------------------
+# shared FISTA / FISTA-Δ / fused-ISTA driver
+# ---------------------------------------------------------------------
+def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backtracking=False, eta=0.5,
+           max_iter=500, tol=0.0, tol_ratio=0.0, adaptive_restart=False, restart_threshold=1.0,
+           grad_tol_check=False, history=None, history_obj=None, x0=None, check_every=None, log=None):
+    """Run the state machine.  Device-driven when nothing needs a per-iteration host decision,
+    host-driven otherwise (grad-norm stop ref:179, backtracking ref:183-197, history ref:224-232)."""
+    st = _core.Fista(prob)
+    x0_dev = None if x0 is None else _core.to_device_vec(x0, prob.device)
+    st.reset(tau, alpha1, alpha2, mode=mode, prox_kind=prox_kind, delta=delta, adaptive_restart=adaptive_restart,
+             restart_threshold=restart_threshold, tol_step=tol if tol > 0.0 else 0.0,
+             tol_ratio=tol_ratio if tol_ratio > 0.0 else 0.0, x0=x0_dev)
+    gtimer = _EventTimer(grad_call_times)
+    host_driven = backtracking or history is not None or log is not None or (grad_tol_check and tol > 0.0)
+    smooth_a2 = alpha2 if (prox_kind == _lib.PROX_L1 and alpha2 > 0) else 0.0
+
+    if not host_driven:
+        stops_possible = tol > 0.0 or tol_ratio > 0.0
+        chunk = max_iter if not stops_possible else max(1, int(check_every or 8))
+        done = 0
+        while done < max_iter:
+            todo = min(chunk, max_iter - done)
+            ev = gtimer.start()
+            st.run(todo)
+            gtimer.stop(ev, todo)
+            done += todo
+            if stops_possible and st.status().stopped != _lib.STOP_NONE:
+                break
+        gtimer.flush()
+        if stops_possible:
+            # only the iterations that really ran count as gradient calls
+            k = int(st.status().k)
+            del grad_call_times[k:]
+        return st
+
+    for _ in range(max_iter):
+        ev = gtimer.start()
+        st.grad()                                            # ref:173-175 (alpha2*y is added by the consumers)
+        gtimer.stop(ev)
+        if grad_tol_check and tol > 0.0:                      # ref:179
+            gn2 = st.trial(tau, with_residual=False)[3]
+            if math.sqrt(gn2) < tol:
+                break
+        if backtracking:                                      # ref:183-197 / ref:298-312 / ref:92-108
+            bt_steps = 0
+            ls_t0 = time.perf_counter()
+            t_k = tau
+            while True:
+                gd, xt2, y2, _, rr_t, rr_y = st.trial(t_k, with_residual=True)
+                lhs = 0.5 * rr_t + 0.5 * smooth_a2 * xt2
+                rhs = 0.5 * rr_y + 0.5 * smooth_a2 * y2 + C * gd
+                if lhs <= rhs:
+                    break
+                t_k *= eta
+                bt_steps += 1
+            ls_call_times.append(time.perf_counter() - ls_t0)
+            ls_call_iters.append(bt_steps)
+            tau = t_k
+            st.set_tau(tau)
+        st.update()                                           # ref:200-221
+        if history is not None or log is not None:
+            xk = st.x_tensor()
+            if history is not None:
+                history["x"].append(_core.from_device_vec(xk, like))
+                history["obj"].append(history_obj(prob, xk))
+            s = st.status()
+            if log is not None:
+                log["x"].append(_core.from_device_vec(xk, like))
+                log["t"].append(tau)
+                log["delta"].append(s.this_step)
+        else:
+            s = st.status() if (tol > 0.0 or tol_ratio > 0.0) else None
+        if s is not None and s.stopped != _lib.STOP_NONE:     # ref:238, :242
+            break
+    gtimer.flush()
+    return st
+
+
+def _objective_by_alpha(alpha1, alpha2):
+    """History objective of fista(): driven by alpha>0, not by reg_type.  ref:225-230"""
+    def obj(prob, xk):
+        rr, x2, x1 = prob.residual_objective(xk)
+        val = 0.5 * rr
+        if alpha2 > 0:
+            val += 0.5 * alpha2 * x2
+        if alpha1 > 0:
+            val += alpha1 * x1
+        return val
+    return obj
+
+
+def _objective_by_reg(reg_type, alpha1, alpha2):
+    """compute_objective semantics (objective_functions.py:3-30), used by fista_delta ref:321."""
+    if reg_type not in ("lasso", "ridge", "elasticnet"):
+        raise ValueError(f"Unsupported reg_type='{reg_type}'")
+
+    def obj(prob, xk):
+        rr, x2, x1 = prob.residual_objective(xk)
+        val = 0.5 * rr
+        if reg_type in ("ridge", "elasticnet"):
+            val += 0.5 * alpha2 * x2
+        if reg_type in ("lasso", "elasticnet"):
+            val += alpha1 * x1
+        return val
+    return obj
+
+
+# ---------------------------------------------------------------------
+# ISTA                                                          ref:65-125
+# ---------------------------------------------------------------------
+def ista(x0, g, grad_g, prox_h, L, backtracking: bool = False, eta: float = 0.5, t_init_factor: float = 1.0,
+         max_iter: int = 500, tol: float = 0.0, return_history: bool = False):
+    """Proximal gradient over callables.  When ``g``/``grad_g`` come from one ``LeastSquares`` object and
+    ``prox_h`` is an ``L1Prox``/``ElasticNetProx`` the fused device state machine runs (single pass over A per
+    gradient); any other callables are invoked as given on float32 device tensors, with the loop's own vector
+    arithmetic still on the device."""
+    reset_metrics()
+    ls = getattr(g, "__self__", g)
+    fused = (isinstance(ls, LeastSquares) and getattr(grad_g, "__self__", None) is ls
+             and isinstance(prox_h, (L1Prox, ElasticNetProx)))
+    t = t_init_factor / L                                                     # ref:81
+    if fused:
+        prob = ls.prob
+        if isinstance(prox_h, ElasticNetProx):
+            if ls.alpha2 != 0.0:
+                fused = False          # l2 both in g and in the prox: not a state-machine configuration
+            else:
+                kind, a1, a2 = _lib.PROX_ENET, prox_h.alpha1, prox_h.alpha2
+        else:
+            kind, a1, a2 = _lib.PROX_L1, prox_h.alpha1, ls.alpha2
+    if fused:
+        x0_dev = _core.to_device_vec(x0, prob.device)
+        log = {"x": [_core.from_device_vec(x0_dev, x0)], "t": [t], "delta": []} if return_history else None
+        st = _drive(prob, x0, mode=_lib.MODE_ISTA, prox_kind=kind, alpha1=a1, alpha2=a2, tau=t,
+                    backtracking=backtracking, eta=eta, max_iter=max_iter, tol=tol, x0=x0_dev, log=log)
+        x = _core.from_device_vec(st.x_tensor(), x0)
+        return (x, log) if return_history else x
+
+    # ---- generic callables on device tensors ----
+    from .operators import vec_axpby, vec_stats
+    x = _core.to_device_vec(x0).clone()                                        # ref:79
+    log = {"x": [_core.from_device_vec(x, x0)], "t": [t], "delta": []} if return_history else None
+    gtimer = _EventTimer(grad_call_times)
+    for _ in range(max_iter):
+        ev = gtimer.start()
+        grad = grad_g(x)                                                        # ref:87-89
+        gtimer.stop(ev)
+        if backtracking:                                                        # ref:92-108
+            bt_steps = 0
+            ls_t0 = time.perf_counter()
+            t_k = t
+            gx = float(g(x))
+            while True:
+                x_new = prox_h(vec_axpby(1.0, x, -t_k, grad), t_k)
+                diff = vec_axpby(1.0, x_new, -1.0, x)
+                gd = vec_stats(None, grad, diff)[1]
+                if float(g(x_new)) <= gx + C * gd:
+                    break
+                t_k *= eta
+                bt_steps += 1
+            ls_call_times.append(time.perf_counter() - ls_t0)
+            ls_call_iters.append(bt_steps)
+            t = t_k
+        else:
+            x_new = prox_h(vec_axpby(1.0, x, -t, grad), t)                      # ref:110-111
+            diff = vec_axpby(1.0, x_new, -1.0, x)
+        delta = math.sqrt(vec_stats(None, None, diff)[2])                        # ref:114
+        x = x_new
+        if return_history:
+            log["x"].append(_core.from_device_vec(x, x0))
+            log["t"].append(t)
+            log["delta"].append(delta)
+        if tol > 0.0 and delta < tol:                                           # ref:122
+            break
+    gtimer.flush()
+    out = _core.from_device_vec(x, x0)
+    return (out, log) if return_history else out
+
+
+# ---------------------------------------------------------------------
+# FISTA                                                        ref:132-245
+# ---------------------------------------------------------------------
+def fista(A, b, reg_type: str, alpha1: float, alpha2: float, backtracking: bool = False, eta: float = 0.5,
+          t_init_factor: float = 1.0, max_iter: int = 500, tol: float = 0.0, tol_ratio: float = 0.0,
+          adaptive_restart: bool = False, restart_threshold: float = 1.0, return_history: bool = False,
+          *, L=None, dtype=None, check_every=None):
+    reset_metrics()
+    prob = _core.as_problem(A, b, dtype)
+    like = prob.like
+    L_val = estimate_lipschitz(prob) if L is None else float(L)               # ref:155
+    if alpha2 > 0:                                                            # ref:156-157
+        L_val += alpha2
+    tau = t_init_factor / L_val                                               # ref:158
+    history = None
+    if return_history:
+        zero = torch.zeros(prob.n, dtype=torch.float32, device=prob.device)
+        history = {"x": [_core.from_device_vec(zero, like)], "obj": []}      # ref:160
+    st = _drive(prob, like, mode=_lib.MODE_FISTA, prox_kind=_lib.PROX_L1, alpha1=alpha1, alpha2=alpha2, tau=tau,
+                backtracking=backtracking, eta=eta, max_iter=max_iter, tol=tol, tol_ratio=tol_ratio,
+                adaptive_restart=adaptive_restart, restart_threshold=restart_threshold, grad_tol_check=True,
+                history=history, history_obj=_objective_by_alpha(alpha1, alpha2), check_every=check_every)
+    x_k = _core.from_device_vec(st.x_tensor(), like)
+    return (x_k, history) if return_history else x_k
+
+
+# ---------------------------------------------------------------------
+# FISTA-Δ                                                      ref:251-344
+# ---------------------------------------------------------------------
+def fista_delta(A, b, reg_type: str, alpha1: float, alpha2: float, delta: float, backtracking: bool = False,
+                eta: float = 0.5, t_init_factor: float = 1.0, max_iter: int = 500, tol: float = 0.0,
+                tol_ratio: float = 0.0, return_history: bool = False, *, L=None, dtype=None, check_every=None):
+    reset_metrics()
+    # Course requirement: delta > 2 for convergence guarantee                   ref:268
+    assert delta > 2, "In FISTA-Δ, delta must be > 2 for convergence (course requirement)"
+    prob = _core.as_problem(A, b, dtype)
+    like = prob.like
+    L_val = estimate_lipschitz(prob) if L is None else float(L)               # ref:273
+    if alpha2 > 0:
+        L_val += alpha2
+    tau = t_init_factor / L_val
+    history = {"x": [], "obj": []} if return_history else None               # ref:279 (no x0 entry)
+    obj = _objective_by_reg(reg_type, alpha1, alpha2) if return_history else None
+    st = _drive(prob, like, mode=_lib.MODE_DELTA, prox_kind=_lib.PROX_L1, alpha1=alpha1, alpha2=alpha2, tau=tau,
+                delta=delta, backtracking=backtracking, eta=eta, max_iter=max_iter, tol=tol, tol_ratio=tol_ratio,
+                grad_tol_check=False, history=history, history_obj=obj, check_every=check_every)
+    x_k = _core.from_device_vec(st.x_tensor(), like)
+    return (x_k, history) if return_history else x_k

@@ -1,0 +1,39 @@
+"""MI355X drop-in for the reference's ``prox_operators.py`` (stand-alone K3 kernels)."""
+import numpy as np
+import torch
+
+from . import _core, _lib
+
+
+def _scalar(tau, name):
+    if isinstance(tau, (torch.Tensor, np.ndarray)):
+        count = tau.size if isinstance(tau, np.ndarray) else tau.numel()
+        if count != 1:
+            raise NotImplementedError(f"{name}: array-valued thresholds are not supported by the device kernel")
+        return float(tau.reshape(-1)[0])
+    return float(tau)
+
+
+def prox_l1(v, tau):
+    """Soft threshold  sign(v)·max(|v| − τ, 0).   prox_operators.py:3-8"""
+    lib = _lib.load()
+    _core.require_gpu()
+    vt = _core.to_device_vec(v)
+    out = torch.empty_like(vt)
+    with torch.cuda.device(vt.device):
+        _lib.check(lib.fos_prox_l1(_core.ptr(vt), _scalar(tau, "prox_l1"), _core.ptr(out), vt.numel(),
+                                   _core.stream_ptr()), "fos_prox_l1")
+    return _core.from_device_vec(out, v) if not isinstance(v, torch.Tensor) else out
+
+
+def prox_elastic_net(v, tau, alpha1, alpha2):
+    """prox_{τ(α₁‖·‖₁ + ½α₂‖·‖²)}(v) = prox_l1(v, τα₁) / (1 + τα₂).   prox_operators.py:10-16"""
+    lib = _lib.load()
+    _core.require_gpu()
+    vt = _core.to_device_vec(v)
+    out = torch.empty_like(vt)
+    with torch.cuda.device(vt.device):
+        _lib.check(lib.fos_prox_elastic_net(_core.ptr(vt), _scalar(tau, "prox_elastic_net"), float(alpha1),
+                                            float(alpha2), _core.ptr(out), vt.numel(), _core.stream_ptr()),
+                   "fos_prox_elastic_net")
+    return _core.from_device_vec(out, v) if not isinstance(v, torch.Tensor) else out

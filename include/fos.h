@@ -1,0 +1,135 @@
+/* fos.h — C ABI of the MI355X-native FISTA / L-BFGS inner loop (libfos_hip.so).
+ *
+ * The reference (ElBaldo1/FastOptSolver) is pure Python/NumPy and has NO FFI layer; the "boundary" it
+ * exposes is a set of Python callables.  Each entry point below names the reference expression it
+ * replaces (file:line in the reference checkout); INTEGRATION.md shows the ctypes binding a maintainer
+ * would add to the reference to route its loops through this library.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (FOS_ERR_*); text via fos_last_error().
+ *   - no C++ exception crosses the boundary; no torch types appear in any signature.
+ *   - all data pointers are DEVICE pointers borrowed from the caller (e.g. tensor.data_ptr()); they must
+ *     outlive the handle that stores them.  `stream` is a hipStream_t passed as void*.
+ *   - calls only ENQUEUE work on the handle's stream unless documented "synchronises".
+ *   - a handle is single-threaded; distinct handles may be used from distinct threads.
+ *   - A is row-major (C order), m rows, n columns, leading dimension lda (elements).
+ */
+#ifndef FOS_H_
+#define FOS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FOS_ABI_VERSION 1
+
+enum { FOS_OK = 0, FOS_ERR_ARG = -1, FOS_ERR_HIP = -2, FOS_ERR_STATE = -3, FOS_ERR_UNSUPPORTED = -4 };
+enum { FOS_F32 = 0, FOS_BF16 = 1 };                    /* element type of A */
+enum { FOS_MODE_FISTA = 0, FOS_MODE_DELTA = 1, FOS_MODE_ISTA = 2 };
+enum { FOS_PROX_L1 = 0, FOS_PROX_ENET = 1 };
+enum { FOS_STOP_NONE = 0, FOS_STOP_STEP = 1, FOS_STOP_RATIO = 2, FOS_STOP_GRAD = 3 };
+
+typedef struct fos_problem fos_problem;   /* A, b, launch plan, workspace            */
+typedef struct fos_fista fos_fista;       /* iterate + momentum state of one solve   */
+
+/* Solver parameters: the keyword arguments of fista() iterative_solvers.py:132-147,
+ * fista_delta() :251-265 and the prox closure of ista() :65-77. */
+typedef struct fos_fista_params {
+  double tau;               /* step t_init_factor / L                     :158, :276, :81        */
+  double alpha1;            /* l1 weight                                   :201                   */
+  double alpha2;            /* l2 weight                                   :174-175 or prox :15   */
+  double delta;             /* FISTA-delta parameter                       :330                   */
+  double restart_threshold; /*                                             :210                   */
+  double tol_step;          /* stop when ||x_next - x_k|| < tol_step       :238, :337  (0 = off)  */
+  double tol_ratio;         /* stop when ratio < tol_ratio                 :242, :341  (0 = off)  */
+  int32_t mode;             /* FOS_MODE_*                                                         */
+  int32_t prox_kind;        /* FOS_PROX_L1: l2 in the gradient; FOS_PROX_ENET: l2 in the prox     */
+  int32_t adaptive_restart; /*                                             :209                   */
+  int32_t reserved;
+} fos_fista_params;
+
+/* Host copy of the device-resident loop state (fos_fista_status synchronises). */
+typedef struct fos_fista_status {
+  double t_prev, beta, this_step, prev_step, ratio;
+  double rr;        /* ||A y - b||^2 of the last gradient   */
+  double gnorm2;    /* ||grad_smooth(y)||^2 of the last update */
+  double xnorm1;    /* ||x_k||_1   */
+  double xnorm2;    /* ||x_k||_2^2 */
+  int64_t k;        /* completed iterations */
+  int32_t stopped;  /* FOS_STOP_* */
+  int32_t restarts;
+} fos_fista_status;
+
+const char* fos_last_error(void);
+int fos_abi_version(void);
+
+/* ---- problem ------------------------------------------------------------------------------------ */
+/* Bind A (m x n, a_dtype) and b (m floats, may be NULL = zero vector, as in estimate_lipschitz
+ * iterative_solvers.py:54).  Allocates the partial-gradient slabs.  Synchronises (allocation). */
+int fos_problem_create(fos_problem** out, const void* A, int64_t m, int64_t n, int64_t lda, int a_dtype,
+                       const float* b, void* stream);
+int fos_problem_destroy(fos_problem* p);
+/* plan[0..7] = {path (0 fused single pass, 1 two-pass fallback), threads, chunks/thread, rows/step,
+ *               workgroups, slabs, nontemporal, CUs} */
+int fos_problem_plan(const fos_problem* p, int32_t plan[8]);
+/* Benchmark/tuning override of the fused-kernel geometry; returns FOS_ERR_UNSUPPORTED if not instantiated. */
+int fos_problem_tune(fos_problem* p, int threads, int chunks, int rows, int workgroups);
+/* Use a caller-owned gradient buffer (n + 4 floats, 16-byte aligned) instead of the internal one, e.g. a
+ * torch tensor that torch.distributed all-reduces between fos_fista_grad and fos_fista_update. */
+int fos_problem_set_gbuf(fos_problem* p, float* gbuf);
+
+/* K2: grad = A^T (A y - b) + alpha2*y ; *rr_out (device double, may be NULL) = ||A y - b||^2.
+ * Replaces iterative_solvers.py:54, :173-175, :292-294 and lbfgs.py:46-51.  A is read ONCE. */
+int fos_gemv_pair(fos_problem* p, const float* y, float alpha2, float* grad, double* rr_out);
+
+/* K5: out3 (device doubles) = { ||A x - b||^2, ||x||_2^2, ||x||_1 } — one pass over A.
+ * Replaces g_smooth iterative_solvers.py:163-168 and compute_objective objective_functions.py:13-24. */
+int fos_residual_objective(fos_problem* p, const float* x, double* out3);
+
+/* Power iteration, iterative_solvers.py:45-60.  v_inout: start vector (n floats, need not be normalised),
+ * overwritten with the last iterate.  Synchronises; *L_out and *iters_out are host values. */
+int fos_power_iter(fos_problem* p, float* v_inout, int n_iter, double tol, double* L_out, int* iters_out);
+
+/* ---- stand-alone prox (K3), prox_operators.py:3-8 and :10-16 --------------------------------------- */
+int fos_prox_l1(const float* v, float thr, float* out, int64_t n, void* stream);
+int fos_prox_elastic_net(const float* v, float tau, float alpha1, float alpha2, float* out, int64_t n, void* stream);
+
+/* ---- FISTA / FISTA-delta / ISTA state machine ------------------------------------------------------- */
+int fos_fista_create(fos_problem* p, fos_fista** out);
+int fos_fista_destroy(fos_fista* f);
+/* x_0 = x0 (device, n floats) or zeros when NULL; t = 1; beta = 0; k = 0.  :149-161, :269-280, :79-81 */
+int fos_fista_reset(fos_fista* f, const fos_fista_params* prm, const float* x0);
+int fos_fista_set_tau(fos_fista* f, double tau);
+/* Enqueue `iters` full iterations (gradient, prox, momentum, restart and stop logic all on the device;
+ * no host round trip).  Iterations after a device-side stop are no-ops.  :170-242, :289-342 */
+int fos_fista_run(fos_fista* f, int iters);
+/* Split form for host-driven control (grad-norm stop :179, backtracking :183-197, sharded runs):
+ *   fos_fista_grad    gbuf[0..n) = A^T (A y_k - b) (WITHOUT alpha2*y), gbuf[n] = ||A y_k - b||^2 (float)
+ *   fos_fista_update  prox + momentum from gbuf (after an optional all-reduce of gbuf[0..n]) */
+int fos_fista_grad(fos_fista* f);
+int fos_fista_update(fos_fista* f);
+/* Armijo trial at step t (:187-191): x_tmp = prox(y_k - t*grad).  Synchronises.  out6 (host) =
+ * { grad.(x_tmp - y), ||x_tmp||^2, ||y||^2, ||grad||^2, ||A x_tmp - b||^2, ||A y_k - b||^2 }, grad including
+ * alpha2*y.  with_residual = 0 skips the pass over A (out6[4] = 0): the cheap way to read ||grad|| (:179). */
+int fos_fista_trial(fos_fista* f, double t, int with_residual, double out6[6]);
+int fos_fista_status_get(fos_fista* f, fos_fista_status* out);   /* synchronises */
+int fos_fista_get_x(fos_fista* f, float* dst);   /* enqueue copy of x_k (n floats) to dst (device)  */
+float* fos_fista_x(fos_fista* f);        /* device pointer to x_k (n floats), borrowed      */
+float* fos_fista_gbuf(fos_fista* f);     /* device pointer to gbuf (n+1 floats), borrowed   */
+
+/* ---- L-BFGS device pieces (the arithmetic behind lbfgs.py:64; spec in SURVEY.md 8c) ----------------- */
+/* K4: d = -H g by the two-loop recursion over the `hist` newest pairs.  S, Y: [cap][n] ring buffers,
+ * slot (head + i) % cap holds the i-th oldest pair.  One launch. */
+int fos_lbfgs_two_loop(const float* g, const float* S, const float* Y, int hist, int head, int cap, int64_t n,
+                       float* d_out, void* stream);
+/* out4 (device doubles) = { x.x, g.d, d.d, max|g| } in one launch. */
+int fos_vec_stats(const float* x, const float* g, const float* d, int64_t n, double* out4, void* stream);
+/* out = a*x + b*y (y may be NULL when b == 0). */
+int fos_vec_axpby(double a, const float* x, double b, const float* y, float* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOS_H_ */

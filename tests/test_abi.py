@@ -1,0 +1,72 @@
+"""CPU: the C-ABI library builds/loads and exports exactly what include/fos.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from fastoptsolver_amd import build, _lib
+    build.build()
+    return _lib.load()
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "fos.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(fos_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_matches_binding_table(lib):
+    from fastoptsolver_amd import _lib
+    assert header_symbols() == sorted(_lib.SIGNATURES), "include/fos.h and _lib.SIGNATURES disagree"
+
+
+def test_every_symbol_exported(lib):
+    from fastoptsolver_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (fos_[a-z0-9_]+)", out))
+    assert set(header_symbols()) <= exported
+    for name in header_symbols():
+        assert getattr(lib, name) is not None
+
+
+def test_version_and_error_paths_without_gpu(lib):
+    assert lib.fos_abi_version() == 1
+    h = ctypes.c_void_p()
+    # argument validation happens before any HIP call
+    rc = lib.fos_problem_create(ctypes.byref(h), None, 4, 4, 4, 0, None, None)
+    assert rc == -1 and b"bad shape" in lib.fos_last_error()
+    rc = lib.fos_prox_l1(None, 0.5, None, 4, None)
+    assert rc == -1
+    rc = lib.fos_lbfgs_two_loop(None, None, None, 0, 0, 0, 8, None, None)
+    assert rc == -1
+
+
+def test_struct_layouts_match_header():
+    from fastoptsolver_amd import _lib
+    assert ctypes.sizeof(_lib.FistaParams) == 7 * 8 + 4 * 4
+    assert ctypes.sizeof(_lib.FistaStatus) == 9 * 8 + 8 + 2 * 4
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "fastoptsolver_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f"{f} imports the oracle"
+                assert "fos_oracle" not in txt, f"{f} references the oracle module"
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    from fastoptsolver_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.FosError):
+        _lib.load()

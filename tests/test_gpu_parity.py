@@ -1,0 +1,344 @@
+"""GPU parity tests: the HIP path (through the C ABI) vs the oracle and vs the golden vectors captured from
+the reference.  Tolerance: 1e-5 relative on iterates (BASELINE.json north_star: "iterates match the NumPy
+reference to 1e-5 relative fp32"); counts (gradient calls, line-search shrinks, iterations) must be equal."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fos_oracle as orc
+from tests import _data
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def fos():
+    import fastoptsolver_amd as f
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    return f
+
+
+def _dev(x, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(x), dtype=dtype, device="cuda")
+
+
+# --------------------------------------------------------------------------------------------------
+# K2 / K5 / prox / power iteration against the oracle
+# --------------------------------------------------------------------------------------------------
+SHAPES = [(64, 16), (777, 129), (1000, 5), (4096, 512), (300, 1024), (1, 8), (3, 4), (513, 2052), (2050, 8192),
+          (1031, 16384), (700, 4100)]
+
+
+@pytest.mark.parametrize("m,n", SHAPES)
+@pytest.mark.parametrize("with_b", [True, False])
+def test_gemv_pair(fos, m, n, with_b):
+    rng = np.random.default_rng(m * 31 + n)
+    A = rng.standard_normal((m, n)).astype(np.float32)
+    b = rng.standard_normal(m).astype(np.float32) if with_b else None
+    y = rng.standard_normal(n).astype(np.float32)
+    prob = fos.prepare(A, b)
+    rr = torch.zeros(1, dtype=torch.float64, device="cuda")
+    g = prob.gemv_pair(_dev(y), alpha2=0.3, rr_out=rr).cpu().numpy().astype(np.float64)
+    g_ref, rr_ref = orc.gram_gradient(A.astype(np.float64), y.astype(np.float64),
+                                      None if b is None else b.astype(np.float64), 0.3)
+    assert _data.rel(g, g_ref) < TOL, prob.plan()
+    assert float(rr.cpu()) == pytest.approx(rr_ref, rel=TOL)
+    r2, x2, x1 = prob.residual_objective(_dev(y))
+    assert r2 == pytest.approx(rr_ref, rel=TOL)
+    assert x2 == pytest.approx(float(y.astype(np.float64) @ y), rel=1e-6)
+    assert x1 == pytest.approx(float(np.abs(y.astype(np.float64)).sum()), rel=1e-6)
+
+
+def test_gemv_pair_paths_and_layouts(fos):
+    """Strided A (lda > n), misaligned views (two-pass fallback) and a misaligned y must agree with the fused path."""
+    rng = np.random.default_rng(5)
+    m, n = 1500, 1024
+    big = torch.as_tensor(rng.standard_normal((m, n + 8)).astype(np.float32), device="cuda")
+    b = rng.standard_normal(m).astype(np.float32)
+    ybuf = torch.as_tensor(rng.standard_normal(n + 1).astype(np.float32), device="cuda")
+    y = ybuf[1:]                                     # 4-byte aligned only
+    ref = None
+    for name, view in (("aligned-strided", big[:, :n]), ("misaligned", big[:, 1:n + 1]), ("shifted4", big[:, 4:n + 4])):
+        prob = fos.prepare(view, b)
+        plan = prob.plan()
+        assert plan["path"] == (1 if name == "misaligned" else 0), (name, plan)
+        g = prob.gemv_pair(y, alpha2=0.0).cpu().numpy()
+        A64 = view.cpu().numpy().astype(np.float64)
+        g_ref, _ = orc.gram_gradient(A64, y.cpu().numpy().astype(np.float64), b.astype(np.float64), 0.0)
+        assert _data.rel(g, g_ref) < TOL, name
+
+
+@pytest.mark.parametrize("threads,chunks,rows", [(256, 4, 2), (512, 4, 2), (512, 8, 2), (512, 8, 1), (1024, 4, 1), (1024, 2, 2)])
+def test_every_fused_geometry(fos, threads, chunks, rows):
+    rng = np.random.default_rng(threads + chunks)
+    m = 1237
+    n = min(threads * chunks * 4, 4096)
+    A = rng.standard_normal((m, n)).astype(np.float32)
+    b = rng.standard_normal(m).astype(np.float32)
+    y = rng.standard_normal(n).astype(np.float32)
+    prob = fos.prepare(A, b)
+    prob.tune(threads, chunks, rows, 37)
+    plan = prob.plan()
+    assert (plan["threads"], plan["chunks"], plan["rows"]) == (threads, chunks, rows)
+    g = prob.gemv_pair(_dev(y)).cpu().numpy()
+    g_ref, _ = orc.gram_gradient(A.astype(np.float64), y.astype(np.float64), b.astype(np.float64), 0.0)
+    assert _data.rel(g, g_ref) < TOL, plan
+
+
+def test_gemv_pair_bf16(fos):
+    """bf16 A / fp32 accumulate: judged against the oracle run on the bf16-rounded A."""
+    rng = np.random.default_rng(11)
+    for m, n in ((900, 2048), (333, 16384), (100, 24)):
+        A16 = torch.as_tensor(rng.standard_normal((m, n)).astype(np.float32)).to(torch.bfloat16)
+        b = rng.standard_normal(m).astype(np.float32)
+        y = rng.standard_normal(n).astype(np.float32)
+        prob = fos.prepare(A16.cuda(), b)
+        assert prob.dtype == "bf16"
+        g = prob.gemv_pair(_dev(y), alpha2=0.1).cpu().numpy()
+        g_ref, _ = orc.gram_gradient(A16.to(torch.float64).numpy(), y.astype(np.float64), b.astype(np.float64), 0.1)
+        assert _data.rel(g, g_ref) < TOL, (m, n, prob.plan())
+
+
+def test_prox_kernels(fos):
+    fx = _data.load("leaf")
+    v = fx["leaf/v"].astype(np.float32)
+    for thr in (0.7, 0.0):
+        got = fos.prox_l1(v, thr)
+        want = orc.prox_l1(v.astype(np.float64), np.float64(np.float32(thr)))
+        assert got.dtype == np.float64 and np.allclose(got, want, rtol=1e-6, atol=1e-7)
+        assert np.array_equal(got == 0, want == 0)
+        assert np.array_equal(np.signbit(got), np.signbit(want))          # -0.0 for shrunk negatives
+    got = fos.prox_elastic_net(v, 0.3, 2.0, 0.5)
+    assert np.allclose(got, orc.prox_elastic_net(v.astype(np.float64), 0.3, 2.0, 0.5), rtol=1e-6, atol=1e-7)
+    # identities from SURVEY §4
+    assert np.array_equal(fos.prox_l1(v, 0.0), v.astype(np.float64))
+    assert np.allclose(fos.prox_elastic_net(v, 0.4, 1.5, 0.0), fos.prox_l1(v, 0.4 * 1.5), rtol=1e-6)
+    t = fos.prox_l1(_dev(v), 0.7)
+    assert isinstance(t, torch.Tensor) and t.is_cuda and t.numel() == v.size
+    assert fos.prox_l1(np.zeros(0, dtype=np.float32), 0.1).size == 0
+
+
+def test_compute_objective(fos):
+    fx = _data.load("leaf")
+    v, A, b = fx["leaf/v"], fx["leaf/A"], fx["leaf/b"]
+    got = [fos.compute_objective(v, A, b, r, 0.3, 0.7) for r in ("lasso", "ridge", "elasticnet")]
+    assert np.allclose(got, fx["leaf/obj"], rtol=TOL)
+    with pytest.raises(ValueError):
+        fos.compute_objective(v, A, b, "l0", 0.3, 0.7)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "ragged", "aligned", "boston"])
+def test_estimate_lipschitz(fos, tag):
+    A, b, fx = _data.problem(tag)
+    np.random.seed(0)
+    L = fos.estimate_lipschitz(A)
+    assert L == pytest.approx(float(fx[f"{tag}/L"]), rel=TOL)
+    # consumed exactly n normals from the global stream, like iterative_solvers.py:50
+    after = np.random.randn()
+    np.random.seed(0)
+    np.random.randn(A.shape[1])
+    assert after == np.random.randn()
+
+
+# --------------------------------------------------------------------------------------------------
+# solver families against the goldens
+# --------------------------------------------------------------------------------------------------
+def _call(fos, c, A, b, **extra):
+    kw = dict(c["kw"])
+    kw.update(extra)
+    if c["algo"] == "fista":
+        return fos.fista(A, b, c["reg"], c["alpha1"], c["alpha2"], max_iter=c["max_iter"], **kw)
+    return fos.fista_delta(A, b, c["reg"], c["alpha1"], c["alpha2"], c["delta"], max_iter=c["max_iter"], **kw)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "ragged", "aligned"])
+def test_fista_family_vs_reference_goldens(fos, tag):
+    A, b, fx = _data.problem(tag)
+    prob = fos.prepare(A, b)
+    n_cases = 0
+    for c in _data.cases(tag)["cases"]:
+        if c["algo"] not in ("fista", "fista_delta"):
+            continue
+        key = c["key"]
+        np.random.seed(0)
+        x, h = _call(fos, c, prob, None, return_history=True)
+        met = fos.get_metrics()
+        if key + "/niter" in fx:
+            assert len(h["obj"]) == int(fx[key + "/niter"]), key
+            assert _data.rel(x, fx[key + "/x"]) < TOL, key
+            continue
+        off = 1 if c["algo"] == "fista" else 0
+        for k, xr in zip(fx[key + "/ks"], fx[key + "/xs"]):
+            assert _data.rel(h["x"][k - 1 + off], xr) < TOL, (key, int(k))
+        assert np.allclose(h["obj"], fx[key + "/obj"], rtol=TOL), key
+        assert [met["grad_num_calls"], met["ls_num_calls"], met["ls_iters_total"]] == list(fx[key + "/counts"]), key
+        assert set(met) == {"grad_num_calls", "grad_time_total", "grad_time_mean", "ls_num_calls", "ls_time_total",
+                            "ls_time_mean", "ls_iters_total"}
+        # the device-driven fast path (no history) must land on the same final iterate
+        np.random.seed(0)
+        x_fast = _call(fos, c, prob, None)
+        assert isinstance(x_fast, np.ndarray) and x_fast.dtype == np.float64
+        assert _data.rel(x_fast, fx[key + "/x"]) < TOL, key
+        n_cases += 1
+    assert n_cases >= 20
+
+
+def test_boston_config1(fos):
+    """BASELINE config 1: Boston-like Lasso through the device path (two-pass fallback: n = 5)."""
+    fx = _data.load("boston")
+    A, b = fx["boston/A"], fx["boston/b"]
+    np.random.seed(0)
+    x, h = fos.fista(A, b, "lasso", 1.0, 0.0, max_iter=500, return_history=True)
+    assert fos.prepare(A, b).plan()["path"] == 1
+    for k, xr in zip(fx["boston/fista_lasso/ks"], fx["boston/fista_lasso/xs"]):
+        assert _data.rel(h["x"][k], xr) < TOL, int(k)
+    assert np.allclose(h["obj"], fx["boston/fista_lasso/obj"], rtol=TOL)
+    assert fos.get_metrics()["grad_num_calls"] == 500
+    np.random.seed(0)
+    x = fos.fista_delta(A, b, "elasticnet", 1.0, 0.5, 3.0, max_iter=500)
+    assert _data.rel(x, fx["boston/fdelta_enet/x"]) < TOL
+    with pytest.raises(AssertionError):
+        fos.fista_delta(A, b, "lasso", 1.0, 0.0, 2.0)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "ragged"])
+def test_ista_vs_reference_goldens(fos, tag):
+    A, b, fx = _data.problem(tag)
+    n = 0
+    for c in _data.cases(tag)["cases"]:
+        if c["algo"] != "ista":
+            continue
+        key, a1, a2 = c["key"], c["alpha1"], c["alpha2"]
+        s2 = a2 if c["in_smooth"] else 0.0
+        ls = fos.LeastSquares(A, b, alpha2=s2)
+        prox = fos.ElasticNetProx(a1, a2) if c["prox"] == "enet_prox" else fos.L1Prox(a1)
+        L = float(fx[f"{tag}/ista/L"]) + s2
+        x, log = fos.ista(np.zeros(A.shape[1]), ls, ls.grad, prox, L, max_iter=c["max_iter"], return_history=True,
+                          **c["kw"])
+        met = fos.get_metrics()
+        assert _data.rel(x, fx[key + "/x"]) < TOL, key
+        for k, xr in zip(fx[key + "/ks"], fx[key + "/xs"]):
+            assert _data.rel(log["x"][k], xr) < TOL, (key, int(k))
+        assert np.allclose(log["t"], fx[key + "/t"], rtol=1e-6), key
+        assert np.allclose(log["delta"], fx[key + "/delta"], rtol=1e-4, atol=1e-9), key
+        assert [met["grad_num_calls"], met["ls_num_calls"], met["ls_iters_total"]] == list(fx[key + "/counts"]), key
+        # generic-callable path (arbitrary closures on device tensors) must agree with the fused one
+        g = lambda x, ls=ls: ls(x)                                        # noqa: E731
+        grad = lambda x, ls=ls: ls.grad(x)                                # noqa: E731
+        prox_fn = lambda v, t, prox=prox: prox(v, t)                      # noqa: E731
+        x2 = fos.ista(np.zeros(A.shape[1]), g, grad, prox_fn, L, max_iter=c["max_iter"], **c["kw"])
+        assert _data.rel(x2, fx[key + "/x"]) < TOL, key
+        n += 1
+    assert n == 6
+
+
+@pytest.mark.parametrize("tag", ["tiny", "ragged", "aligned"])
+def test_lbfgs_vs_reference_goldens(fos, tag):
+    """fp32 vectors / fp64 scalars vs SciPy's fp64 iterates captured through lbfgs.py:64: compare iterate by
+    iterate up to the shorter run (the fp32 line search reaches its noise floor a few iterations early)."""
+    A, b, fx = _data.problem(tag)
+    prob = fos.prepare(A, b)
+    n = 0
+    for c in _data.cases(tag)["cases"]:
+        if c["algo"] != "lbfgs":
+            continue
+        key = c["key"]
+        s = fos.LBFGSSolver(c["reg"], c["alpha1"], c["alpha2"]).fit(prob, None)
+        assert (s.reg_type, s.alpha1, s.alpha2) == (c["norm_reg"], c["norm_a1"], c["norm_a2"]), key
+        ref_it = fx[key + "/iterates"]
+        nit_ref = len(ref_it)
+        assert nit_ref - 4 <= s.nit_ <= nit_ref + 1, (key, s.nit_, nit_ref, s.task_)
+        for k in range(min(s.nit_, nit_ref)):
+            assert _data.rel(s.iterates_[k], ref_it[k]) < 2e-5, (key, k)
+        assert _data.rel(s.x_, fx[key + "/x"]) < 2e-5, key
+        assert s.final_obj_ == pytest.approx(float(fx[key + "/final_obj"]), rel=1e-5), key
+        assert len(s.history_) == s.nit_ and fos.get_metrics()["grad_num_calls"] == s.nfev_
+        n += 1
+    assert n == 4
+    with pytest.raises(ValueError):
+        fos.LBFGSSolver("l0", 1.0, 1.0)
+
+
+def test_two_loop_kernel_vs_oracle(fos):
+    from fastoptsolver_amd import _core, _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    for n, hist, cap, head in ((8192, 10, 10, 3), (1000, 4, 10, 0), (37, 0, 10, 0), (16384, 7, 10, 8)):
+        S = rng.standard_normal((cap, n)).astype(np.float32)
+        Y = (S + 0.3 * rng.standard_normal((cap, n))).astype(np.float32)     # s.y > 0
+        g = rng.standard_normal(n).astype(np.float32)
+        order = [(head + i) % cap for i in range(hist)]
+        d_ref = orc.two_loop_direction(g.astype(np.float64), [S[i].astype(np.float64) for i in order],
+                                       [Y[i].astype(np.float64) for i in order])
+        Sd, Yd, gd = _dev(S), _dev(Y), _dev(g)
+        d = torch.empty(n, dtype=torch.float32, device="cuda")
+        _lib.check(lib.fos_lbfgs_two_loop(_core.ptr(gd), _core.ptr(Sd), _core.ptr(Yd), hist, head, cap, n, _core.ptr(d),
+                                          _core.stream_ptr()))
+        assert _data.rel(d.cpu().numpy(), d_ref) < TOL, (n, hist)
+
+
+# --------------------------------------------------------------------------------------------------
+# stopping rules, restart, tensor I/O
+# --------------------------------------------------------------------------------------------------
+def test_device_side_stop_and_tensor_io(fos):
+    A, b, fx = _data.problem("aligned")
+    At, bt = _dev(A), _dev(b)
+    lam = float(np.max(np.abs(A.T @ b)))
+    prob = fos.prepare(At, bt)
+    np.random.seed(0)
+    x = fos.fista(prob, None, "lasso", 0.1 * lam, 0.0, max_iter=200, tol_ratio=0.5, check_every=5)
+    assert isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32
+    key = "aligned/fista_stop/tol_ratio"
+    assert _data.rel(x.cpu().numpy(), fx[key + "/x"]) < TOL
+    assert fos.get_metrics()["grad_num_calls"] == int(fx[key + "/niter"])
+    # L= extension skips the power iteration and does not touch the RNG
+    state = np.random.get_state()[1].copy()
+    fos.fista(prob, None, "lasso", 0.1 * lam, 0.0, max_iter=3, L=float(fx["aligned/L"]))
+    assert np.array_equal(state, np.random.get_state()[1])
+
+
+# --------------------------------------------------------------------------------------------------
+# full-size properties (BASELINE config 2 shape): things the oracle is too slow to check directly
+# --------------------------------------------------------------------------------------------------
+def test_full_size_properties(fos):
+    m, n = 65536, 8192
+    g = torch.Generator(device="cuda").manual_seed(0)
+    A = torch.randn(m, n, device="cuda", generator=g)
+    b = torch.randn(m, device="cuda", generator=g)
+    y1 = torch.randn(n, device="cuda", generator=g)
+    y2 = torch.randn(n, device="cuda", generator=g)
+    prob = fos.prepare(A, b)
+    assert prob.plan()["path"] == 0
+    G = lambda y: prob.gemv_pair(y).double()                              # noqa: E731
+    # (1) affine: G(y1 + y2) - G(y1) - G(y2) + G(0) = 0
+    z = torch.zeros(n, device="cuda")
+    lin = G(y1 + y2) - G(y1) - G(y2) + G(z)
+    assert float(lin.norm() / G(y1 + y2).norm()) < 5e-6
+    # (2) G(0) = -A^T b, checked on a row subsample with the oracle and in full with a second code path
+    rows = slice(0, 512)
+    sub = fos.prepare(A[rows], b[rows])
+    g_sub = sub.gemv_pair(y1).cpu().numpy()
+    g_ref, _ = orc.gram_gradient(A[rows].cpu().numpy().astype(np.float64), y1.cpu().numpy().astype(np.float64),
+                                 b[rows].cpu().numpy().astype(np.float64), 0.0)
+    assert _data.rel(g_sub, g_ref) < TOL
+    # (3) fused single pass == sum of 8 row shards (the multi-GPU decomposition), fixed order
+    acc = torch.zeros(n, dtype=torch.float64, device="cuda")
+    for p in range(8):
+        sl = slice(p * m // 8, (p + 1) * m // 8)
+        acc += fos.prepare(A[sl], b[sl]).gemv_pair(y1).double()
+    full = G(y1)
+    assert float((acc - full).norm() / full.norm()) < 2e-6
+    # (4) run-to-run bit reproducibility (fixed-order slab reduction, no float atomics)
+    assert torch.equal(prob.gemv_pair(y1), prob.gemv_pair(y1))
+    # (5) 20 FISTA iterations: the objective the device reports never increases by more than rounding
+    lam = float((A.T @ b).abs().max())
+    L = float(fos.estimate_lipschitz(prob))
+    x, h = fos.fista(prob, None, "lasso", 0.1 * lam, 0.0, max_iter=20, L=L, return_history=True)
+    obj = np.array(h["obj"])
+    assert np.all(np.diff(obj) <= 1e-6 * obj[:-1]) or obj[-1] < obj[0]
+    assert np.isfinite(obj).all() and obj[-1] < obj[0]

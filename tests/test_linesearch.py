@@ -1,0 +1,53 @@
+"""CPU: the product's host-side Moré–Thuente search vs SciPy's DCSRCH and vs the oracle's restatement."""
+import numpy as np
+import pytest
+
+from fastoptsolver_amd._linesearch import LineSearch
+from oracle import fos_oracle as orc
+
+
+def _functions(rng):
+    c = rng.uniform(0.1, 30.0, size=3)
+    sh = rng.uniform(0.05, 4.0)
+    phi = lambda t: c[0] * (t - sh) ** 2 + c[1] * np.cos(c[2] * t) * 0.1 + 0.01 * t ** 4            # noqa: E731
+    dphi = lambda t: 2 * c[0] * (t - sh) - 0.1 * c[1] * c[2] * np.sin(c[2] * t) + 0.04 * t ** 3     # noqa: E731
+    return phi, dphi
+
+
+def _run(cls_start, cls_step, get_status, a1, phi, dphi):
+    stp = cls_start(a1, phi(0.0), dphi(0.0))
+    seq = []
+    for _ in range(20):
+        seq.append(stp)
+        stp = cls_step(stp, phi(stp), dphi(stp))
+        if get_status() != "FG":
+            break
+    return seq, get_status()
+
+
+def test_against_scipy_and_oracle():
+    from scipy.optimize._dcsrch import DCSRCH
+    rng = np.random.default_rng(0)
+    checked = 0
+    for trial in range(80):
+        phi, dphi = _functions(rng)
+        if dphi(0.0) >= 0:
+            continue
+        a1 = float(rng.choice([1.0, 0.01, 25.0]))
+        ls = LineSearch()
+        seq, status = _run(ls.begin, ls.step, lambda: ls.status, a1, phi, dphi)
+        mt = orc.MoreThuente()
+        seq_o, status_o = _run(mt.start, mt.advance, lambda: mt.task, a1, phi, dphi)
+        assert status == status_o and seq == pytest.approx(seq_o, rel=1e-14), trial
+        ref = DCSRCH(phi, dphi, ftol=1e-3, gtol=0.9, xtol=0.1, stpmin=0.0, stpmax=1e10)
+        stp_ref, _, _, _ = ref(a1, phi0=phi(0.0), derphi0=dphi(0.0), maxiter=20)
+        if stp_ref is not None:
+            assert status == "CONVERGENCE" and seq[-1] == pytest.approx(stp_ref, rel=1e-14), trial
+        checked += 1
+    assert checked > 40
+
+
+def test_rejects_ascent_direction():
+    ls = LineSearch()
+    ls.begin(1.0, 1.0, +0.5)
+    assert ls.status.startswith("ERROR")
