@@ -37,9 +37,11 @@ def to_device_vec(x, device=None):
 
 
 def from_device_vec(t, like):
-    """Return `t` as the same kind of object the caller handed in (ndarray float64 / tensor)."""
+    """Return `t` as the same kind of object the caller handed in: ndarray float64, or a tensor on t's device
+    in the caller's floating dtype (bf16 inputs get float32 back)."""
     if is_tensor(like):
-        return t.clone()
+        dt = like.dtype if like.dtype in (torch.float32, torch.float64) else torch.float32
+        return t.to(dt).clone() if t.dtype == dt else t.to(dt)
     return t.detach().to("cpu", torch.float64).numpy()
 
 
@@ -108,12 +110,14 @@ class Problem:
         """grad = A^T (A y - b) + alpha2 y (device tensor); rr_out: optional 1-element float64 device tensor."""
         if out is None:
             out = torch.empty(self.n, dtype=torch.float32, device=self.device)
+        y = to_device_vec(y, self.device)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.fos_gemv_pair(self.h, ptr(y), float(alpha2), ptr(out), ptr(rr_out)), "fos_gemv_pair")
         return out
 
     def residual_objective(self, x):
-        """Host tuple (||Ax-b||^2, ||x||^2, ||x||_1); synchronises."""
+        """Host tuple (||Ax-b||^2, ||x||^2, ||x||_1); synchronises.  x is rounded to fp32 for the pass over A."""
+        x = to_device_vec(x, self.device)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.fos_residual_objective(self.h, ptr(x), ptr(self.scratch)), "fos_residual_objective")
         v = self.scratch[:3].cpu()
@@ -188,10 +192,11 @@ class Fista:
             _lib.check(self.lib.fos_fista_update(self.h), "fos_fista_update")
 
     def trial(self, t, with_residual=True):
-        out = (C.c_double * 6)()
+        out = (C.c_double * 8)()
         with torch.cuda.device(self.prob.device):
             _lib.check(self.lib.fos_fista_trial(self.h, float(t), int(bool(with_residual)), out), "fos_fista_trial")
-        return list(out)
+        keys = ("gd", "dd", "nnz", "gnorm2", "y2", "q", "rr_y")
+        return dict(zip(keys, list(out)))
 
     def status(self):
         st = _lib.FistaStatus()
@@ -200,8 +205,8 @@ class Fista:
         return st
 
     def x_tensor(self):
-        """Copy of x_k as a device tensor."""
-        out = torch.empty(self.prob.n, dtype=torch.float32, device=self.prob.device)
+        """Copy of x_k as a float64 device tensor."""
+        out = torch.empty(self.prob.n, dtype=torch.float64, device=self.prob.device)
         with torch.cuda.device(self.prob.device):
             _lib.check(self.lib.fos_fista_get_x(self.h, ptr(out)), "fos_fista_get_x")
         return out

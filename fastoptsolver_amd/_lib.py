@@ -49,7 +49,7 @@ SIGNATURES = {
     "fos_fista_run": (_i32, [_vp, _i32]),
     "fos_fista_grad": (_i32, [_vp]),
     "fos_fista_update": (_i32, [_vp]),
-    "fos_fista_trial": (_i32, [_vp, _f64, _i32, C.POINTER(_f64)]),
+    "fos_fista_trial": (_i32, [_vp, _f64, _i32, C.POINTER(_f64)]),   # out8
     "fos_fista_status_get": (_i32, [_vp, C.POINTER(FistaStatus)]),
     "fos_fista_get_x": (_i32, [_vp, _vp]),
     "fos_fista_x": (_vp, [_vp]),

@@ -113,7 +113,8 @@ struct fos_problem {
 struct fos_fista {
   fos_problem* p = nullptr;
   fos::FistaParams prm{};
-  float *x_cur = nullptr, *x_prev = nullptr, *x_tmp = nullptr;
+  double *x_cur = nullptr, *x_prev = nullptr;   // fp64 iterate state
+  float* dlt = nullptr;                         // trial difference vector x_tmp - y_k (fp32)
   fos::FistaScalars* scal = nullptr;
   double* out5 = nullptr;            // device
   int nupd = 0;                      // workgroups of the update kernel
@@ -360,16 +361,16 @@ int fos_power_iter(fos_problem* p, float* v_inout, int n_iter, double tol, doubl
 }
 
 int fos_prox_l1(const float* v, float thr, float* out, int64_t n, void* stream) {
-  if (!v || !out || n < 0) return fail(FOS_ERR_ARG, "fos_prox_l1: bad argument");
   if (n == 0) return FOS_OK;
+  if (!v || !out || n < 0) return fail(FOS_ERR_ARG, "fos_prox_l1: bad argument");
   hipLaunchKernelGGL(fos::prox_l1_kernel, dim3(grid_1d(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, v, thr, out, n);
   LAUNCH_CHECK();
   return FOS_OK;
 }
 
 int fos_prox_elastic_net(const float* v, float tau, float alpha1, float alpha2, float* out, int64_t n, void* stream) {
-  if (!v || !out || n < 0) return fail(FOS_ERR_ARG, "fos_prox_elastic_net: bad argument");
   if (n == 0) return FOS_OK;
+  if (!v || !out || n < 0) return fail(FOS_ERR_ARG, "fos_prox_elastic_net: bad argument");
   hipLaunchKernelGGL(fos::prox_enet_kernel, dim3(grid_1d(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, v, tau,
                      alpha1, alpha2, out, n);
   LAUNCH_CHECK();
@@ -381,10 +382,10 @@ int fos_fista_create(fos_problem* p, fos_fista** out) {
   if (!p || !out) return fail(FOS_ERR_ARG, "fos_fista_create: null");
   fos_fista* f = new fos_fista();
   f->p = p;
-  const size_t nb = (size_t)p->n * sizeof(float);
+  const size_t nb = (size_t)p->n * sizeof(double);
   hipError_t he = hipMalloc(&f->x_cur, nb);
   if (he == hipSuccess) he = hipMalloc(&f->x_prev, nb);
-  if (he == hipSuccess) he = hipMalloc(&f->x_tmp, nb);
+  if (he == hipSuccess) he = hipMalloc(&f->dlt, (size_t)p->n * sizeof(float));
   if (he == hipSuccess) he = hipMalloc(&f->scal, sizeof(fos::FistaScalars));
   if (he == hipSuccess) he = hipMalloc(&f->out5, 8 * sizeof(double));
   if (he != hipSuccess) {
@@ -398,7 +399,7 @@ int fos_fista_create(fos_problem* p, fos_fista** out) {
 
 int fos_fista_destroy(fos_fista* f) {
   if (!f) return FOS_OK;
-  void* bufs[] = {f->x_cur, f->x_prev, f->x_tmp, f->scal, f->out5};
+  void* bufs[] = {f->x_cur, f->x_prev, f->dlt, f->scal, f->out5};
   for (void* q : bufs)
     if (q) (void)hipFree(q);
   delete f;
@@ -406,25 +407,26 @@ int fos_fista_destroy(fos_fista* f) {
 }
 
 static void to_dev_params(const fos_fista_params* s, fos::FistaParams* d) {
-  d->alpha1 = (float)s->alpha1;
-  d->alpha2 = (float)s->alpha2;
-  d->tau = (float)s->tau;
+  d->alpha1 = s->alpha1;
+  d->alpha2 = s->alpha2;
+  d->tau = s->tau;
   d->mode = s->mode;
   d->prox_kind = s->prox_kind;
-  d->delta = (float)s->delta;
+  d->delta = s->delta;
   d->adaptive_restart = s->adaptive_restart;
-  d->restart_threshold = (float)s->restart_threshold;
+  d->restart_threshold = s->restart_threshold;
   d->tol_step = s->tol_step;
   d->tol_ratio = s->tol_ratio;
+  d->pad = 0;
 }
 
-int fos_fista_reset(fos_fista* f, const fos_fista_params* prm, const float* x0) {
+int fos_fista_reset(fos_fista* f, const fos_fista_params* prm, const double* x0) {
   if (!f || !prm) return fail(FOS_ERR_ARG, "fos_fista_reset: null");
   if (prm->mode < 0 || prm->mode > 2 || prm->prox_kind < 0 || prm->prox_kind > 1 || !(prm->tau > 0.0))
     return fail(FOS_ERR_ARG, "fos_fista_reset: bad mode/prox_kind/tau");
   to_dev_params(prm, &f->prm);
   fos_problem* p = f->p;
-  const size_t nb = (size_t)p->n * sizeof(float);
+  const size_t nb = (size_t)p->n * sizeof(double);
   if (x0) {
     HIP_TRY(hipMemcpyAsync(f->x_cur, x0, nb, hipMemcpyDeviceToDevice, p->stream));
     HIP_TRY(hipMemcpyAsync(f->x_prev, x0, nb, hipMemcpyDeviceToDevice, p->stream));
@@ -442,7 +444,7 @@ int fos_fista_reset(fos_fista* f, const fos_fista_params* prm, const float* x0) 
 
 int fos_fista_set_tau(fos_fista* f, double tau) {
   if (!f || !(tau > 0.0)) return fail(FOS_ERR_ARG, "fos_fista_set_tau: bad argument");
-  f->prm.tau = (float)tau;
+  f->prm.tau = tau;
   return FOS_OK;
 }
 
@@ -466,12 +468,10 @@ int fos_fista_run(fos_fista* f, int iters) {
     if ((rc = launch_pass(p, fista_source(f), p->b, true, &n_rr))) return rc;
     if (p->vec4)
       hipLaunchKernelGGL((fos::fista_update_kernel<true, true>), dim3(f->nupd), dim3(256), 0, p->stream, p->slabs,
-                         p->nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, (float*)nullptr, f->scal,
-                         f->prm, p->part);
+                         p->nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, p->part);
     else
       hipLaunchKernelGGL((fos::fista_update_kernel<true, false>), dim3(f->nupd), dim3(256), 0, p->stream, p->slabs,
-                         p->nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, (float*)nullptr, f->scal,
-                         f->prm, p->part);
+                         p->nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, p->part);
     LAUNCH_CHECK();
     if ((rc = launch_finalize(f, n_rr))) return rc;
   }
@@ -491,35 +491,33 @@ int fos_fista_update(fos_fista* f) {
   fos_problem* p = f->p;
   if (p->vec4)
     hipLaunchKernelGGL((fos::fista_update_kernel<false, true>), dim3(f->nupd), dim3(256), 0, p->stream,
-                       (const float*)nullptr, 0, p->gbuf, (int)p->n, f->x_cur, f->x_prev, (float*)nullptr, f->scal,
-                       f->prm, p->part);
+                       (const float*)nullptr, 0, p->gbuf, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, p->part);
   else
     hipLaunchKernelGGL((fos::fista_update_kernel<false, false>), dim3(f->nupd), dim3(256), 0, p->stream,
-                       (const float*)nullptr, 0, p->gbuf, (int)p->n, f->x_cur, f->x_prev, (float*)nullptr, f->scal,
-                       f->prm, p->part);
+                       (const float*)nullptr, 0, p->gbuf, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, p->part);
   LAUNCH_CHECK();
   return launch_finalize(f, 0);
 }
 
-int fos_fista_trial(fos_fista* f, double t, int with_residual, double out6[6]) {
-  if (!f || !out6 || !(t > 0.0)) return fail(FOS_ERR_ARG, "fos_fista_trial: bad argument");
+int fos_fista_trial(fos_fista* f, double t, int with_residual, double out8[8]) {
+  if (!f || !out8 || !(t > 0.0)) return fail(FOS_ERR_ARG, "fos_fista_trial: bad argument");
   fos_problem* p = f->p;
   const int grid = grid_1d(p->n, 256, 256);
   HIP_TRY(hipMemsetAsync(f->out5, 0, 8 * sizeof(double), p->stream));
   hipLaunchKernelGGL(fos::fista_trial_kernel, dim3(grid), dim3(256), 0, p->stream, p->gbuf, (int)p->n, f->x_cur,
-                     f->x_prev, f->scal, f->prm, (float)t, f->x_tmp, (float*)nullptr, p->part);
-  hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(64), 0, p->stream, p->part, grid, 4, f->out5);
+                     f->x_prev, f->scal, f->prm, t, f->dlt, p->part);
+  hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(64), 0, p->stream, p->part, grid, fos::TRIAL_W, f->out5);
   LAUNCH_CHECK();
   // rr(y_k) was produced by fos_fista_grad; copy it before the trial pass reuses the partial buffer
-  HIP_TRY(hipMemcpyAsync(f->out5 + 5, &f->scal->rr, sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(f->out5 + 6, &f->scal->rr, sizeof(double), hipMemcpyDeviceToDevice, p->stream));
   if (with_residual) {
-    YSource ys{f->x_tmp, nullptr, nullptr, nullptr, nullptr};
+    YSource ys{f->dlt, nullptr, nullptr, nullptr, nullptr};
     int n_rr = 0, rc;
-    if ((rc = launch_pass(p, ys, p->b, false, &n_rr))) return rc;
-    hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(64), 0, p->stream, p->rr_part, n_rr, 1, f->out5 + 4);
+    if ((rc = launch_pass(p, ys, nullptr, false, &n_rr))) return rc;        // ||A dlt||^2  (b = 0)
+    hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(64), 0, p->stream, p->rr_part, n_rr, 1, f->out5 + 5);
     LAUNCH_CHECK();
   }
-  HIP_TRY(hipMemcpyAsync(out6, f->out5, 6 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipMemcpyAsync(out8, f->out5, 8 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   return FOS_OK;
 }
@@ -535,12 +533,12 @@ int fos_fista_status_get(fos_fista* f, fos_fista_status* out) {
   return FOS_OK;
 }
 
-int fos_fista_get_x(fos_fista* f, float* dst) {
+int fos_fista_get_x(fos_fista* f, double* dst) {
   if (!f || !dst) return fail(FOS_ERR_ARG, "fos_fista_get_x: null");
-  HIP_TRY(hipMemcpyAsync(dst, f->x_cur, (size_t)f->p->n * sizeof(float), hipMemcpyDeviceToDevice, f->p->stream));
+  HIP_TRY(hipMemcpyAsync(dst, f->x_cur, (size_t)f->p->n * sizeof(double), hipMemcpyDeviceToDevice, f->p->stream));
   return FOS_OK;
 }
-float* fos_fista_x(fos_fista* f) { return f ? f->x_cur : nullptr; }
+double* fos_fista_x(fos_fista* f) { return f ? f->x_cur : nullptr; }
 float* fos_fista_gbuf(fos_fista* f) { return f ? f->p->gbuf : nullptr; }
 
 // ---- L-BFGS pieces ---------------------------------------------------------------------------------------

@@ -25,14 +25,19 @@ namespace fos {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// Momentum scalars the FISTA prologue needs to rebuild y_k = x_k + beta (x_k - x_prev) in registers.
+// Where the kernel takes y from.  The FISTA iterate state (x_k, x_{k-1}) is kept in fp64 on the device: the
+// n-vectors are negligible traffic, and an fp32 state alone costs 1e-4 of parity on ill-conditioned data
+// (DESIGN.md "Precision").  y_k = x_k + beta (x_k - x_prev) is formed in fp64 and rounded ONCE to fp32 for the
+// pass over A.
 struct YSource {
   const float* y;        // explicit y (power iteration, L-BFGS, trial points) or nullptr
-  const float* x_cur;    // x_k
-  const float* x_prev;   // x_{k-1}
+  const double* x_cur;   // x_k
+  const double* x_prev;  // x_{k-1}
   const double* beta;    // device scalar
   const int* stopped;    // device flag: non-zero -> kernel is a no-op (solver already stopped)
 };
+
+__device__ inline double form_y(double xc, double xp, double beta) { return xc + beta * (xc - xp); }
 
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<float> {
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
   float yv[K][EPC];
   float gv[K][EPC];
   bool live[K];
-  const float beta = (ys.y == nullptr) ? (float)(*ys.beta) : 0.f;
+  const double beta = (ys.y == nullptr) ? *ys.beta : 0.0;
 #pragma unroll
   for (int c = 0; c < K; ++c) {
     const int col = (c * THREADS + tid) * EPC;
@@ -112,11 +117,10 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
           const f32x4 t = *reinterpret_cast<const f32x4*>(ys.y + col + 4 * q);
           yv[c][4 * q + 0] = t.x; yv[c][4 * q + 1] = t.y; yv[c][4 * q + 2] = t.z; yv[c][4 * q + 3] = t.w;
         } else {
-          const f32x4 xc = *reinterpret_cast<const f32x4*>(ys.x_cur + col + 4 * q);
-          const f32x4 xp = *reinterpret_cast<const f32x4*>(ys.x_prev + col + 4 * q);
-          // same expression as reduce_update.hpp::form_y -> bitwise identical y in both kernels
-          yv[c][4 * q + 0] = xc.x + beta * (xc.x - xp.x); yv[c][4 * q + 1] = xc.y + beta * (xc.y - xp.y);
-          yv[c][4 * q + 2] = xc.z + beta * (xc.z - xp.z); yv[c][4 * q + 3] = xc.w + beta * (xc.w - xp.w);
+          // same form_y as the update kernel -> both kernels see the same y_k
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            yv[c][4 * q + e] = (float)form_y(ys.x_cur[col + 4 * q + e], ys.x_prev[col + 4 * q + e], beta);
         }
       }
     }
@@ -223,6 +227,8 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
 // ---------------------------------------------------------------------------------------------------------
 // Shape-generic two-pass fallback (any n, any lda, any alignment): correctness path for ragged problems
 // such as the 1000 x 5 Boston design (config 1).  Pass 1: one wave per row -> r.  Pass 2: thread per column.
+// Not bandwidth-critical, so both passes accumulate in fp64 (products of two floats are exact in a double):
+// the ill-conditioned config-1 data (cond(A^T A) ~ 1e9) then tracks the fp64 reference to < 1e-5.
 // ---------------------------------------------------------------------------------------------------------
 template <typename T> __device__ inline float elem_to_float(T v);
 template <> __device__ inline float elem_to_float<float>(float v) { return v; }
@@ -236,21 +242,21 @@ __global__ __launch_bounds__(256) void residual_rows_kernel(const T* __restrict_
   if (ys.stopped != nullptr && *ys.stopped != 0) return;
   __shared__ double wsum[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float beta = (ys.y == nullptr) ? (float)(*ys.beta) : 0.f;
+  const double beta = (ys.y == nullptr) ? *ys.beta : 0.0;
   double rr = 0.0;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < m; row += (int64_t)gridDim.x * 4) {
     const T* ar = A + row * lda;
-    float acc = 0.f;
+    double acc = 0.0;
     for (int j = lane; j < n; j += 64) {
       float yj;
       if (ys.y != nullptr) yj = ys.y[j];
-      else { const float xc = ys.x_cur[j], xp = ys.x_prev[j]; yj = xc + beta * (xc - xp); }
-      acc = fmaf(elem_to_float<T>(ar[j]), yj, acc);
+      else yj = (float)form_y(ys.x_cur[j], ys.x_prev[j], beta);
+      acc += (double)elem_to_float<T>(ar[j]) * (double)yj;
     }
     acc = wave_sum(acc);
-    if (b != nullptr) acc -= b[row];
-    if (lane == 0) r_out[row] = acc;
-    rr += (double)acc * (double)acc;
+    if (b != nullptr) acc -= (double)b[row];
+    if (lane == 0) r_out[row] = (float)acc;
+    rr += acc * acc;
   }
   if (lane == 0) wsum[wave] = rr;
   __syncthreads();
@@ -268,9 +274,9 @@ __global__ __launch_bounds__(256) void transpose_rows_kernel(const T* __restrict
   int64_t hi = lo + rows_per_chunk;
   if (hi > m) hi = m;
   if (j >= n) return;
-  float acc = 0.f;
-  for (int64_t row = lo; row < hi; ++row) acc = fmaf(elem_to_float<T>(A[row * lda + j]), r[row], acc);
-  slabs[(int64_t)blockIdx.y * n + j] = acc;
+  double acc = 0.0;
+  for (int64_t row = lo; row < hi; ++row) acc += (double)elem_to_float<T>(A[row * lda + j]) * (double)r[row];
+  slabs[(int64_t)blockIdx.y * n + j] = (float)acc;
 }
 
 }  // namespace fos

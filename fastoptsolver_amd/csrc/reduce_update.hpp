@@ -38,19 +38,24 @@ struct FistaScalars {
 };
 
 struct FistaParams {
-  float alpha1;
-  float alpha2;        // smooth l2 weight (added to the gradient) when prox_kind == PROX_L1
-  float tau;           // step
-  int mode;            // MODE_*
-  int prox_kind;       // PROX_*
-  float delta;         // FISTA-delta parameter
-  int adaptive_restart;
-  float restart_threshold;
+  double alpha1;
+  double alpha2;       // smooth l2 weight (added to the gradient) when prox_kind == PROX_L1
+  double tau;          // step
+  double delta;        // FISTA-delta parameter
+  double restart_threshold;
   double tol_step;     // stop when this_step < tol_step   (0 = off)
   double tol_ratio;    // stop when ratio < tol_ratio       (0 = off)
+  int mode;            // MODE_*
+  int prox_kind;       // PROX_*
+  int adaptive_restart;
+  int pad;
 };
 
-__device__ inline float form_y(float xc, float xp, float beta) { return xc + beta * (xc - xp); }
+__device__ inline double soft_threshold(double v, double thr) {
+  double mag = fabs(v) - thr;
+  mag = (mag < 0.0) ? 0.0 : mag;
+  return v == 0.0 ? 0.0 : copysign(mag, v);
+}
 
 __device__ inline float soft_threshold(float v, float thr) {
   // sign(v) * max(|v| - thr, 0)  (prox_operators.py:8): NaN propagates, shrunk negatives give -0.0,
@@ -159,15 +164,14 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 template <bool FROM_SLABS, bool VEC>
 __global__ __launch_bounds__(256) void fista_update_kernel(const float* __restrict__ slabs, int nslabs,
                                                           const float* __restrict__ gbuf, int n,
-                                                          float* __restrict__ x_cur, float* __restrict__ x_prev,
-                                                          float* __restrict__ g_full_out,
+                                                          double* __restrict__ x_cur, double* __restrict__ x_prev,
                                                           const FistaScalars* __restrict__ scal, FistaParams prm,
                                                           double* __restrict__ part) {
   if (scal->stopped != 0) return;
   __shared__ f32x4 lds[RG][RQ];
   __shared__ double dl[4 * 4];
   const int col0 = blockIdx.x * RCOLS;
-  const float beta = (float)scal->beta;
+  const double beta = scal->beta;
   float g[4] = {0.f, 0.f, 0.f, 0.f};
   int col, cnt = 0;
   bool owner;
@@ -190,24 +194,23 @@ __global__ __launch_bounds__(256) void fista_update_kernel(const float* __restri
     cnt = owner ? 1 : 0;
   }
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  const float thr = prm.tau * prm.alpha1;
-  const float shrink = 1.0f / (1.0f + prm.tau * prm.alpha2);
+  const double thr = prm.tau * prm.alpha1;
+  const double shrink = 1.0 / (1.0 + prm.tau * prm.alpha2);
   for (int e = 0; e < cnt; ++e) {
-    const float xc = x_cur[col + e], xp = x_prev[col + e];
-    const float y = form_y(xc, xp, beta);
-    float gf = g[e];
-    if (prm.prox_kind == PROX_L1 && prm.alpha2 > 0.f) gf = fmaf(prm.alpha2, y, gf);
-    const float v = y - prm.tau * gf;
-    float xn = prm.alpha1 > 0.f ? soft_threshold(v, thr) : v;
-    if (prm.prox_kind == PROX_ENET) xn = (prm.alpha1 > 0.f ? xn : v) * shrink;
-    const float d = xn - xc;
-    acc[0] += (double)d * (double)d;
-    acc[1] += (double)gf * (double)gf;
-    acc[2] += fabs((double)xn);
-    acc[3] += (double)xn * (double)xn;
+    const double xc = x_cur[col + e], xp = x_prev[col + e];
+    const double y = form_y(xc, xp, beta);
+    double gf = (double)g[e];
+    if (prm.prox_kind == PROX_L1 && prm.alpha2 > 0.0) gf += prm.alpha2 * y;
+    const double v = y - prm.tau * gf;
+    double xn = prm.alpha1 > 0.0 ? soft_threshold(v, thr) : v;
+    if (prm.prox_kind == PROX_ENET) xn *= shrink;
+    const double d = xn - xc;
+    acc[0] += d * d;
+    acc[1] += gf * gf;
+    acc[2] += fabs(xn);
+    acc[3] += xn * xn;
     x_prev[col + e] = xc;
     x_cur[col + e] = xn;
-    if (g_full_out != nullptr) g_full_out[col + e] = gf;
   }
   block_sum_256<4>(acc, dl);
   if (threadIdx.x == 0) {
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(64) void fista_finalize_kernel(const double* __rest
   if (prm.mode == MODE_FISTA) {
     const double t = scal->t_prev;
     double t_new;
-    if (prm.adaptive_restart && ratio > (double)prm.restart_threshold) {
+    if (prm.adaptive_restart && ratio > prm.restart_threshold) {
       t_new = 1.0;
       beta = 0.0;
       scal->restarts += 1;
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(64) void fista_finalize_kernel(const double* __rest
     scal->t_prev = t_new;
   } else if (prm.mode == MODE_DELTA) {
     const double kk = (double)(scal->k + 1);
-    beta = kk / (kk + 1.0 + (double)prm.delta);
+    beta = kk / (kk + 1.0 + prm.delta);
   }
   scal->beta = beta;
   scal->prev_step = prev;
@@ -267,39 +270,46 @@ __global__ __launch_bounds__(64) void fista_finalize_kernel(const double* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Backtracking trial (iterative_solvers.py:187-191): x_tmp = prox(y - t*g_full), and the three scalars the
-// Armijo test needs besides g(x_tmp):  out = {g_full . (x_tmp - y), ||x_tmp||^2, ||y||^2, ||g_full||^2}.
-// Single workgroup per RCOLS*4 columns; partials folded by trial_finalize.
+// Backtracking trial (iterative_solvers.py:187-191) in cancellation-free form.
+//
+// The reference tests  g(x_tmp) <= g(y) + C * grad.(x_tmp - y)  by evaluating g twice and subtracting two nearly
+// equal numbers.  g is quadratic, so with  dlt = x_tmp - y  the same test is, exactly,
+//        (1 - C) * grad.dlt + 0.5 * ||A dlt||^2 + 0.5 * alpha2 * ||dlt||^2  <=  0 .
+// This kernel forms x_tmp = prox(y - t*grad) in fp64 and writes only dlt (as fp32: dlt keeps full RELATIVE
+// precision however small it is, which x_tmp = y + dlt would lose); ||A dlt||^2 is one residual pass (K5, b = 0).
+// out per workgroup: { grad.dlt, ||dlt||^2, #(dlt != 0), ||grad||^2, ||y||^2 }, grad including alpha2*y.
 // ---------------------------------------------------------------------------------------------------------
+constexpr int TRIAL_W = 5;
 __global__ __launch_bounds__(256) void fista_trial_kernel(const float* __restrict__ gbuf, int n,
-                                                         const float* __restrict__ x_cur,
-                                                         const float* __restrict__ x_prev,
+                                                         const double* __restrict__ x_cur,
+                                                         const double* __restrict__ x_prev,
                                                          const FistaScalars* __restrict__ scal, FistaParams prm,
-                                                         float t_trial, float* __restrict__ x_tmp,
-                                                         float* __restrict__ y_out, double* __restrict__ part) {
-  __shared__ double dl[4 * 4];
-  const float beta = (float)scal->beta;
-  const float thr = t_trial * prm.alpha1;
-  const float shrink = 1.0f / (1.0f + t_trial * prm.alpha2);
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                                                         double t_trial, float* __restrict__ dlt_out,
+                                                         double* __restrict__ part) {
+  __shared__ double dl[TRIAL_W * 4];
+  const double beta = scal->beta;
+  const double thr = t_trial * prm.alpha1;
+  const double shrink = 1.0 / (1.0 + t_trial * prm.alpha2);
+  double acc[TRIAL_W] = {0.0, 0.0, 0.0, 0.0, 0.0};
   for (int col = blockIdx.x * 256 + threadIdx.x; col < n; col += gridDim.x * 256) {
-    const float y = form_y(x_cur[col], x_prev[col], beta);
-    float gf = gbuf[col];
-    if (prm.prox_kind == PROX_L1 && prm.alpha2 > 0.f) gf = fmaf(prm.alpha2, y, gf);
-    const float v = y - t_trial * gf;
-    float xt = prm.alpha1 > 0.f ? soft_threshold(v, thr) : v;
-    if (prm.prox_kind == PROX_ENET) xt = (prm.alpha1 > 0.f ? xt : v) * shrink;
-    x_tmp[col] = xt;
-    if (y_out != nullptr) y_out[col] = y;
-    acc[0] += (double)gf * ((double)xt - (double)y);
-    acc[1] += (double)xt * (double)xt;
-    acc[2] += (double)y * (double)y;
-    acc[3] += (double)gf * (double)gf;
+    const double y = form_y(x_cur[col], x_prev[col], beta);
+    double gf = (double)gbuf[col];
+    if (prm.prox_kind == PROX_L1 && prm.alpha2 > 0.0) gf += prm.alpha2 * y;
+    const double v = y - t_trial * gf;
+    double xt = prm.alpha1 > 0.0 ? soft_threshold(v, thr) : v;
+    if (prm.prox_kind == PROX_ENET) xt *= shrink;
+    const double d = xt - y;
+    dlt_out[col] = (float)d;
+    acc[0] += gf * d;
+    acc[1] += d * d;
+    acc[2] += (d != 0.0) ? 1.0 : 0.0;
+    acc[3] += gf * gf;
+    acc[4] += y * y;
   }
-  block_sum_256<4>(acc, dl);
+  block_sum_256<TRIAL_W>(acc, dl);
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) part[blockIdx.x * 4 + i] = acc[i];
+    for (int i = 0; i < TRIAL_W; ++i) part[blockIdx.x * TRIAL_W + i] = acc[i];
   }
 }
 

@@ -21,6 +21,8 @@ from .operators import ElasticNetProx, L1Prox, LeastSquares
 
 # ref:11 — Armijo sufficient-decrease constant, read at call time (callers may monkey-patch it)
 C: float = 1e-2
+_EPS64 = float(np.finfo(np.float64).eps)
+_EPS32 = float(np.finfo(np.float32).eps)
 
 # ref:16-18 — module-level metric lists (seconds; device time where a kernel is what was timed)
 grad_call_times = []
@@ -97,7 +99,7 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
     """Run the state machine.  Device-driven when nothing needs a per-iteration host decision,
     host-driven otherwise (grad-norm stop ref:179, backtracking ref:183-197, history ref:224-232)."""
     st = _core.Fista(prob)
-    x0_dev = None if x0 is None else _core.to_device_vec(x0, prob.device)
+    x0_dev = None if x0 is None else _core.to_device_vec(x0, prob.device).double()
     st.reset(tau, alpha1, alpha2, mode=mode, prox_kind=prox_kind, delta=delta, adaptive_restart=adaptive_restart,
              restart_threshold=restart_threshold, tol_step=tol if tol > 0.0 else 0.0,
              tol_ratio=tol_ratio if tol_ratio > 0.0 else 0.0, x0=x0_dev)
@@ -129,18 +131,28 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
         st.grad()                                            # ref:173-175 (alpha2*y is added by the consumers)
         gtimer.stop(ev)
         if grad_tol_check and tol > 0.0:                      # ref:179
-            gn2 = st.trial(tau, with_residual=False)[3]
-            if math.sqrt(gn2) < tol:
+            if math.sqrt(st.trial(tau, with_residual=False)["gnorm2"]) < tol:
                 break
         if backtracking:                                      # ref:183-197 / ref:298-312 / ref:92-108
             bt_steps = 0
             ls_t0 = time.perf_counter()
             t_k = tau
             while True:
-                gd, xt2, y2, _, rr_t, rr_y = st.trial(t_k, with_residual=True)
-                lhs = 0.5 * rr_t + 0.5 * smooth_a2 * xt2
-                rhs = 0.5 * rr_y + 0.5 * smooth_a2 * y2 + C * gd
-                if lhs <= rhs:
+                # g(x_tmp) - g(y) - C*grad.dlt, evaluated without cancellation (g is quadratic; fos.h).
+                tr = st.trial(t_k, with_residual=True)
+                excess = (1.0 - C) * tr["gd"] + 0.5 * tr["q"] + 0.5 * smooth_a2 * tr["dd"]
+                # Resolution of this test: (a) the reference compares two float64 evaluations of g, so
+                # differences below eps64*g(y) read as "equal" there (and x_tmp == y ends its loop);
+                # (b) our gradient comes from an fp32 pass over A, so grad.dlt is only known to
+                # ~eps32*||grad||*||dlt|| (Cauchy-Schwarz bound times the rounding level) - at a converged
+                # fixed point dlt is pure gradient noise and must not trigger a step collapse.
+                # (c) a trial step shorter than t*||delta grad|| ~ t*eps32*||grad|| lies inside the noise ball of
+                # y_k: its direction is rounding noise, the decision is meaningless and the step harmless -
+                # this is the fp32-gradient counterpart of the reference's exact "x_tmp == y" exit.
+                g_y = 0.5 * tr["rr_y"] + 0.5 * smooth_a2 * tr["y2"]
+                noise = max(_EPS64 * g_y, 8.0 * _EPS32 * math.sqrt(tr["gnorm2"] * tr["dd"]))
+                in_noise_ball = tr["dd"] <= (8.0 * _EPS32 * t_k) ** 2 * tr["gnorm2"]
+                if tr["nnz"] == 0 or excess <= noise or in_noise_ball:
                     break
                 t_k *= eta
                 bt_steps += 1
@@ -220,7 +232,7 @@ def ista(x0, g, grad_g, prox_h, L, backtracking: bool = False, eta: float = 0.5,
         else:
             kind, a1, a2 = _lib.PROX_L1, prox_h.alpha1, ls.alpha2
     if fused:
-        x0_dev = _core.to_device_vec(x0, prob.device)
+        x0_dev = _core.to_device_vec(x0, prob.device).double()
         log = {"x": [_core.from_device_vec(x0_dev, x0)], "t": [t], "delta": []} if return_history else None
         st = _drive(prob, x0, mode=_lib.MODE_ISTA, prox_kind=kind, alpha1=a1, alpha2=a2, tau=t,
                     backtracking=backtracking, eta=eta, max_iter=max_iter, tol=tol, x0=x0_dev, log=log)
@@ -284,7 +296,7 @@ def fista(A, b, reg_type: str, alpha1: float, alpha2: float, backtracking: bool 
     tau = t_init_factor / L_val                                               # ref:158
     history = None
     if return_history:
-        zero = torch.zeros(prob.n, dtype=torch.float32, device=prob.device)
+        zero = torch.zeros(prob.n, dtype=torch.float64, device=prob.device)
         history = {"x": [_core.from_device_vec(zero, like)], "obj": []}      # ref:160
     st = _drive(prob, like, mode=_lib.MODE_FISTA, prox_kind=_lib.PROX_L1, alpha1=alpha1, alpha2=alpha2, tau=tau,
                 backtracking=backtracking, eta=eta, max_iter=max_iter, tol=tol, tol_ratio=tol_ratio,

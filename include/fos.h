@@ -99,8 +99,10 @@ int fos_prox_elastic_net(const float* v, float tau, float alpha1, float alpha2, 
 /* ---- FISTA / FISTA-delta / ISTA state machine ------------------------------------------------------- */
 int fos_fista_create(fos_problem* p, fos_fista** out);
 int fos_fista_destroy(fos_fista* f);
-/* x_0 = x0 (device, n floats) or zeros when NULL; t = 1; beta = 0; k = 0.  :149-161, :269-280, :79-81 */
-int fos_fista_reset(fos_fista* f, const fos_fista_params* prm, const float* x0);
+/* x_0 = x0 (device, n DOUBLES) or zeros when NULL; t = 1; beta = 0; k = 0.  :149-161, :269-280, :79-81
+ * The iterate state x_k, x_{k-1} is fp64 on the device (n-vectors are negligible traffic; an fp32 state alone
+ * costs 1e-4 of parity on ill-conditioned data).  y_k is rounded once to fp32 for the pass over A. */
+int fos_fista_reset(fos_fista* f, const fos_fista_params* prm, const double* x0);
 int fos_fista_set_tau(fos_fista* f, double tau);
 /* Enqueue `iters` full iterations (gradient, prox, momentum, restart and stop logic all on the device;
  * no host round trip).  Iterations after a device-side stop are no-ops.  :170-242, :289-342 */
@@ -110,13 +112,16 @@ int fos_fista_run(fos_fista* f, int iters);
  *   fos_fista_update  prox + momentum from gbuf (after an optional all-reduce of gbuf[0..n]) */
 int fos_fista_grad(fos_fista* f);
 int fos_fista_update(fos_fista* f);
-/* Armijo trial at step t (:187-191): x_tmp = prox(y_k - t*grad).  Synchronises.  out6 (host) =
- * { grad.(x_tmp - y), ||x_tmp||^2, ||y||^2, ||grad||^2, ||A x_tmp - b||^2, ||A y_k - b||^2 }, grad including
- * alpha2*y.  with_residual = 0 skips the pass over A (out6[4] = 0): the cheap way to read ||grad|| (:179). */
-int fos_fista_trial(fos_fista* f, double t, int with_residual, double out6[6]);
+/* Armijo trial at step t (:187-191) in cancellation-free form.  With x_tmp = prox(y_k - t*grad) and
+ * dlt = x_tmp - y_k the reference's test g(x_tmp) <= g(y_k) + C*grad.dlt is, exactly (g is quadratic),
+ *     (1 - C)*grad.dlt + 0.5*||A dlt||^2 + 0.5*alpha2*||dlt||^2 <= 0.
+ * Synchronises.  out8 (host) = { grad.dlt, ||dlt||^2, #(dlt != 0), ||grad||^2, ||y_k||^2, ||A dlt||^2,
+ * ||A y_k - b||^2, 0 }, grad including alpha2*y.  with_residual = 0 skips the pass over A (out8[5] = 0): the
+ * cheap way to read ||grad|| for the gradient-norm stop (:179). */
+int fos_fista_trial(fos_fista* f, double t, int with_residual, double out8[8]);
 int fos_fista_status_get(fos_fista* f, fos_fista_status* out);   /* synchronises */
-int fos_fista_get_x(fos_fista* f, float* dst);   /* enqueue copy of x_k (n floats) to dst (device)  */
-float* fos_fista_x(fos_fista* f);        /* device pointer to x_k (n floats), borrowed      */
+int fos_fista_get_x(fos_fista* f, double* dst);  /* enqueue copy of x_k (n doubles) to dst (device) */
+double* fos_fista_x(fos_fista* f);       /* device pointer to x_k (n doubles), borrowed     */
 float* fos_fista_gbuf(fos_fista* f);     /* device pointer to gbuf (n+1 floats), borrowed   */
 
 /* ---- L-BFGS device pieces (the arithmetic behind lbfgs.py:64; spec in SURVEY.md 8c) ----------------- */

@@ -86,6 +86,7 @@ def run_fista_family(tag, A, b, store, seed=0, max_iter=60):
             store[key + "/obj"] = np.array(h["obj"])
             store[key + "/x"] = x
             store[key + "/counts"] = np.array([met["grad_num_calls"], met["ls_num_calls"], met["ls_iters_total"]])
+            store[key + "/ls_iters"] = np.array(ref_its.ls_call_iters, dtype=np.int64)
             cases.append(dict(key=key, algo="fista", reg=reg, alpha1=a1, alpha2=a2, max_iter=max_iter, kw=kw))
             if "adaptive_restart" in kw:
                 continue
@@ -99,6 +100,7 @@ def run_fista_family(tag, A, b, store, seed=0, max_iter=60):
             store[key + "/obj"] = np.array(h["obj"])
             store[key + "/x"] = x
             store[key + "/counts"] = np.array([met["grad_num_calls"], met["ls_num_calls"], met["ls_iters_total"]])
+            store[key + "/ls_iters"] = np.array(ref_its.ls_call_iters, dtype=np.int64)
             cases.append(dict(key=key, algo="fista_delta", reg=reg, alpha1=a1, alpha2=a2, delta=3.0,
                               max_iter=max_iter, kw=kwd))
     # stopping rules (iterative_solvers.py:179, :238, :242)
@@ -159,6 +161,7 @@ def run_ista(tag, A, b, store, max_iter=40):
             store[key + "/delta"] = np.array(log["delta"])
             store[key + "/x"] = x
             store[key + "/counts"] = np.array([met["grad_num_calls"], met["ls_num_calls"], met["ls_iters_total"]])
+            store[key + "/ls_iters"] = np.array(ref_its.ls_call_iters, dtype=np.int64)
             cases.append(dict(key=key, algo="ista", prox=pname, alpha1=a1, alpha2=a2, in_smooth=in_smooth,
                               max_iter=max_iter, kw=kw))
     return cases
@@ -252,6 +255,7 @@ def main():
         store[key + "/obj"] = np.array(h["obj"])
         store[key + "/x"] = x
         store[key + "/counts"] = np.array([met["grad_num_calls"], met["ls_num_calls"], met["ls_iters_total"]])
+        store[key + "/ls_iters"] = np.array(ref_its.ls_call_iters, dtype=np.int64)
         cases.append(dict(key=key, algo=fn.__name__, args=list(args), kw=kw))
     cases += run_lbfgs("boston", A, b, store)
     np.savez_compressed(os.path.join(OUT, "boston.npz"), **store)
