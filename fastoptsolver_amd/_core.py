@@ -105,6 +105,16 @@ class Problem:
     def tune(self, threads, chunks, rows, workgroups=0):
         _lib.check(self.lib.fos_problem_tune(self.h, threads, chunks, rows, workgroups), "fos_problem_tune")
 
+    def profile(self, enable=True):
+        _lib.check(self.lib.fos_problem_profile(self.h, int(bool(enable))), "fos_problem_profile")
+
+    def profile_read(self):
+        """(device milliseconds, launches) of the A-pass kernel since the last read; synchronises."""
+        ms, cnt = C.c_double(), C.c_int64()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fos_problem_profile_read(self.h, C.byref(ms), C.byref(cnt)), "fos_problem_profile_read")
+        return ms.value, cnt.value
+
     # ---- kernels -------------------------------------------------------------------------------------
     def gemv_pair(self, y, alpha2=0.0, out=None, rr_out=None):
         """grad = A^T (A y - b) + alpha2 y (device tensor); rr_out: optional 1-element float64 device tensor."""

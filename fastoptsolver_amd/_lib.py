@@ -37,6 +37,8 @@ SIGNATURES = {
     "fos_problem_plan": (_i32, [_vp, C.POINTER(C.c_int32)]),
     "fos_problem_tune": (_i32, [_vp, _i32, _i32, _i32, _i32]),
     "fos_problem_set_gbuf": (_i32, [_vp, _vp]),
+    "fos_problem_profile": (_i32, [_vp, _i32]),
+    "fos_problem_profile_read": (_i32, [_vp, C.POINTER(_f64), C.POINTER(_i64)]),
     "fos_gemv_pair": (_i32, [_vp, _vp, _f32, _vp, _vp]),
     "fos_residual_objective": (_i32, [_vp, _vp, _vp]),
     "fos_power_iter": (_i32, [_vp, _vp, _i32, _f64, C.POINTER(_f64), C.POINTER(_i32)]),

@@ -108,6 +108,12 @@ struct fos_problem {
   double* dscal = nullptr;           // 128 device doubles (scalars, power-iteration history)
   double* part = nullptr;            // partial sums of the small kernels
   int part_cap = 0;
+  // optional kernel timing (fos_problem_profile)
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;   // pairs: [2i] start, [2i+1] stop
+  size_t ev_used = 0;
+  double prof_ms = 0.0;
+  int64_t prof_launches = 0;
 };
 
 struct fos_fista {
@@ -161,8 +167,47 @@ int ensure_workspace(fos_problem* p) {
   return FOS_OK;
 }
 
+int prof_drain(fos_problem* p) {
+  if (p->ev_used == 0) return FOS_OK;
+  HIP_TRY(hipEventSynchronize(p->ev_pool[p->ev_used - 1]));
+  for (size_t i = 0; i + 1 < p->ev_used; i += 2) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, p->ev_pool[i], p->ev_pool[i + 1]));
+    p->prof_ms += ms;
+    p->prof_launches += 1;
+  }
+  p->ev_used = 0;
+  return FOS_OK;
+}
+
+int prof_mark(fos_problem* p, bool start) {
+  if (!p->profiling) return FOS_OK;
+  if (start && p->ev_used + 2 > p->ev_pool.size()) {
+    if (p->ev_pool.size() >= 8192) {          // bounded pool: fold what we have (synchronises)
+      int rc = prof_drain(p);
+      if (rc) return rc;
+    } else {
+      for (int i = 0; i < 2; ++i) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        p->ev_pool.push_back(e);
+      }
+    }
+  }
+  HIP_TRY(hipEventRecord(p->ev_pool[p->ev_used++], p->stream));
+  return FOS_OK;
+}
+
 // Enqueue the A pass for `ys`.  with_g: also produce the slabs (A^T r).  Returns number of rr partials.
+int launch_pass_inner(fos_problem* p, const YSource& ys, const float* b, bool with_g, int* n_rr);
 int launch_pass(fos_problem* p, const YSource& ys, const float* b, bool with_g, int* n_rr) {
+  int rc = prof_mark(p, true);
+  if (rc) return rc;
+  if ((rc = launch_pass_inner(p, ys, b, with_g, n_rr))) return rc;
+  return prof_mark(p, false);
+}
+
+int launch_pass_inner(fos_problem* p, const YSource& ys, const float* b, bool with_g, int* n_rr) {
   if (p->path == 0) {
     FusedLaunch fn = with_g ? p->entry->with_g : p->entry->resid_only;
     fn(p->A, p->lda, b, p->m, (int)p->n, ys, p->rows_per_wg, p->slabs, p->rr_part, p->nwg, p->stream);
@@ -260,8 +305,26 @@ int fos_problem_create(fos_problem** out, const void* A, int64_t m, int64_t n, i
   return FOS_OK;
 }
 
+int fos_problem_profile(fos_problem* p, int enable) {
+  if (!p) return fail(FOS_ERR_ARG, "fos_problem_profile: null");
+  p->profiling = enable != 0;
+  return FOS_OK;
+}
+
+int fos_problem_profile_read(fos_problem* p, double* ms_total, int64_t* launches) {
+  if (!p || !ms_total || !launches) return fail(FOS_ERR_ARG, "fos_problem_profile_read: null");
+  int rc = prof_drain(p);
+  if (rc) return rc;
+  *ms_total = p->prof_ms;
+  *launches = p->prof_launches;
+  p->prof_ms = 0.0;
+  p->prof_launches = 0;
+  return FOS_OK;
+}
+
 int fos_problem_destroy(fos_problem* p) {
   if (!p) return FOS_OK;
+  for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   void* bufs[] = {p->slabs, p->rr_part, p->rvec, p->gbuf_own, p->ybuf, p->dscal, p->part};
   for (void* q : bufs)
     if (q) (void)hipFree(q);

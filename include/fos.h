@@ -80,6 +80,13 @@ int fos_problem_tune(fos_problem* p, int threads, int chunks, int rows, int work
  * torch tensor that torch.distributed all-reduces between fos_fista_grad and fos_fista_update. */
 int fos_problem_set_gbuf(fos_problem* p, float* gbuf);
 
+/* Kernel timing for roofline reports: while enabled, every launch of the fused single-pass kernel (or of the
+ * two fallback kernels) is bracketed by a pair of hipEvents recorded on the handle's stream.
+ * fos_problem_profile_read synchronises, returns the accumulated device milliseconds and the number of
+ * bracketed launches since the last read, and resets both. */
+int fos_problem_profile(fos_problem* p, int enable);
+int fos_problem_profile_read(fos_problem* p, double* ms_total, int64_t* launches);
+
 /* K2: grad = A^T (A y - b) + alpha2*y ; *rr_out (device double, may be NULL) = ||A y - b||^2.
  * Replaces iterative_solvers.py:54, :173-175, :292-294 and lbfgs.py:46-51.  A is read ONCE. */
 int fos_gemv_pair(fos_problem* p, const float* y, float alpha2, float* grad, double* rr_out);
