@@ -228,6 +228,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scale-ref", action="store_true")
     ap.add_argument("--geometry", type=str, default="", help="THREADSxCHUNKSxROWSxWORKGROUPS override (tuning)")
+    ap.add_argument("--rows", type=int, default=0, help="override m (rehearsal / tuning only; reported in config)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -239,15 +240,24 @@ def main():
                      "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # REHEARSAL ONLY (FOS_BENCH_BACKEND=gloo): lets N ranks share one GPU on a 1-GPU box to exercise the N>1 code
+    # path (sharding, barriers, all-reduce, JSON); its numbers are meaningless and are labelled as such.
+    backend = os.environ.get("FOS_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     name = args.workload or ("cfg2" if world == 1 else "cfg4")
+    if args.rows:
+        WORKLOADS[name] = dict(WORKLOADS[name], m=int(args.rows))
     res = run_workload(name, args, rank, world, device, args.steps, args.warmup,
                        want_cpu=not args.no_cpu_baseline, dist=dist)
     scale_ref = None
@@ -283,6 +293,8 @@ def main():
                 "collective": "RCCL all-reduce(SUM) of n+1 fp32 per iteration" if world > 1 else "none",
                 "kernel_plan": res["plan"],
                 "iterate_state": "fp64 on device; y rounded once to fp32 for the single pass over A",
+                "backend": backend if world > 1 else None,
+                "rehearsal": bool(args.rows) or (world > 1 and backend != "nccl"),
             },
             "roofline": {
                 "bound": "hbm",

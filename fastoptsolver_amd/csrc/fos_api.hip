@@ -40,11 +40,11 @@ using fos::YSource;
 typedef void (*FusedLaunch)(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw,
                             float* slabs, double* rr_part, int nwg, hipStream_t st);
 
-template <typename T, int THREADS, int K, int R, int MINW, bool WITH_G>
+template <typename T, int THREADS, int K, int R, int MINW, bool WITH_G, int NBUF>
 void fused_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, float* slabs,
                   double* rr_part, int nwg, hipStream_t st) {
-  hipLaunchKernelGGL((fos::gemv_pair_kernel<T, THREADS, K, R, true, MINW, WITH_G>), dim3(nwg), dim3(THREADS), 0, st,
-                     reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part);
+  hipLaunchKernelGGL((fos::gemv_pair_kernel<T, THREADS, K, R, true, MINW, WITH_G, NBUF, false>), dim3(nwg),
+                     dim3(THREADS), 0, st, reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part);
 }
 
 struct MenuEntry {
@@ -52,15 +52,18 @@ struct MenuEntry {
   FusedLaunch with_g, resid_only;
 };
 #define ENTRY(DT, T, TH, K, R, W) \
-  { DT, TH, K, R, fused_launch<T, TH, K, R, W, true>, fused_launch<T, TH, K, R, W, false> }
+  { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, 2>, fused_launch<T, TH, K, R, W, false, 2> }
+// NB register tiles in flight (profiles/r01_kbench_exp_*.log: 3 tiles are worth 1.5 % at n = 8192)
+#define ENTRY_NB(DT, T, TH, K, R, W, NB) \
+  { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, NB>, fused_launch<T, TH, K, R, W, false, NB> }
 // Ordered by capacity (threads*k*EPC columns); first entry that fits n is the default.
 const MenuEntry kMenu[] = {
     ENTRY(FOS_F32, float, 256, 1, 4, 2),   ENTRY(FOS_F32, float, 256, 2, 4, 2),  ENTRY(FOS_F32, float, 256, 4, 2, 2),
-    ENTRY(FOS_F32, float, 512, 4, 2, 2),   ENTRY(FOS_F32, float, 512, 8, 1, 2),  ENTRY(FOS_F32, float, 512, 8, 2, 2),
+    ENTRY_NB(FOS_F32, float, 512, 4, 2, 2, 3),   ENTRY(FOS_F32, float, 512, 8, 1, 2),  ENTRY(FOS_F32, float, 512, 8, 2, 2),
     ENTRY(FOS_F32, float, 1024, 4, 1, 4),  ENTRY(FOS_F32, float, 1024, 2, 2, 4),
     ENTRY(FOS_BF16, fos::bf16_t, 256, 1, 4, 2), ENTRY(FOS_BF16, fos::bf16_t, 256, 2, 2, 2),
-    ENTRY(FOS_BF16, fos::bf16_t, 256, 4, 2, 2), ENTRY(FOS_BF16, fos::bf16_t, 512, 4, 2, 2),
-    ENTRY(FOS_BF16, fos::bf16_t, 1024, 2, 2, 4),
+    ENTRY(FOS_BF16, fos::bf16_t, 256, 4, 2, 2), ENTRY(FOS_BF16, fos::bf16_t, 1024, 2, 2, 4),
+    ENTRY(FOS_BF16, fos::bf16_t, 512, 4, 2, 2),
 };
 
 const MenuEntry* find_entry(int dtype, int threads, int k, int r) {
@@ -610,8 +613,18 @@ int fos_lbfgs_two_loop(const float* g, const float* S, const float* Y, int hist,
   if (!g || !d_out || n <= 0 || hist < 0 || hist > fos::LB_MAXHIST || cap < hist || (hist > 0 && (!S || !Y)) ||
       head < 0 || (cap > 0 && head >= cap))
     return fail(FOS_ERR_ARG, "fos_lbfgs_two_loop: bad argument");
-  hipLaunchKernelGGL(fos::lbfgs_two_loop_kernel, dim3(1), dim3(fos::LB_THREADS), 0, (hipStream_t)stream, g, S, Y, hist,
-                     head, std::max(cap, 1), n, d_out);
+  // q in registers when the vectors are float4-addressable and short enough; otherwise the generic form.
+  const bool vec = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(S) |
+                                      reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(d_out)) & 15u) == 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int capk = std::max(cap, 1);
+#define FOS_TL(NQ) hipLaunchKernelGGL(fos::lbfgs_two_loop_kernel<NQ>, dim3(1), dim3(fos::LB_THREADS), 0, st, g, S, Y, \
+                                      hist, head, capk, n, d_out)
+  if (vec && n <= 4096) FOS_TL(1);
+  else if (vec && n <= 8192) FOS_TL(2);
+  else if (vec && n <= 16384) FOS_TL(4);
+  else FOS_TL(0);
+#undef FOS_TL
   LAUNCH_CHECK();
   return FOS_OK;
 }

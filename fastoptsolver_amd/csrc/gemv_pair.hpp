@@ -81,7 +81,10 @@ __device__ inline double wave_sum(double v) {
 // Requirements (checked on the host): n % EPC == 0, lda % EPC == 0, A 16-byte aligned, n <= K*THREADS*EPC.
 // Rows of workgroup w: [w*rows_per_wg, min(m, (w+1)*rows_per_wg)).
 // WITH_G = false gives the residual-only pass (K5: ||A x - b||^2 for objectives / Armijo trials).
-template <typename T, int THREADS, int K, int R, bool NT, int MINW, bool WITH_G = true>
+// NBUF register tiles (NBUF-1 steps in flight behind the one being consumed).  IL = true deals rows to the
+// workgroups round-robin in R-row groups (all CUs stream one contiguous window) instead of one contiguous
+// block per workgroup; rows_per_wg is then ignored.
+template <typename T, int THREADS, int K, int R, bool NT, int MINW, bool WITH_G = true, int NBUF = 2, bool IL = false>
 __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
     const T* __restrict__ A, int64_t lda, const float* __restrict__ b, int64_t m, int n, YSource ys,
     int64_t rows_per_wg, float* __restrict__ slabs, double* __restrict__ rr_part) {
@@ -95,8 +98,8 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int64_t row_lo = (int64_t)blockIdx.x * rows_per_wg;
-  int64_t row_hi = row_lo + rows_per_wg;
+  const int64_t row_lo = IL ? 0 : (int64_t)blockIdx.x * rows_per_wg;
+  int64_t row_hi = IL ? m : row_lo + rows_per_wg;
   if (row_hi > m) row_hi = m;
 
   // ---- prologue: this thread's slice of y, straight into registers --------------------------------
@@ -127,16 +130,18 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
   }
 
   const int64_t nrows = row_hi - row_lo;           // may be <= 0 for trailing workgroups
-  const int64_t nsteps = nrows > 0 ? (nrows + R - 1) / R : 0;
+  const int64_t group = (int64_t)R * (IL ? gridDim.x : 1);   // rows between consecutive steps of this workgroup
+  const int64_t first = IL ? (int64_t)blockIdx.x * R : 0;
+  const int64_t nsteps = nrows > first ? (nrows - first + group - 1) / group : 0;
   const char* base = reinterpret_cast<const char*>(A) + (int64_t)tid * 16;
   const int64_t row_bytes = lda * (int64_t)sizeof(T);
   double rr = 0.0;
 
-  u32x4 tile[2][R][K];
+  u32x4 tile[NBUF][R][K];
   auto issue = [&](int buf, int64_t step) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      int64_t row = row_lo + step * R + r;
+      int64_t row = row_lo + first + step * group + r;
       if (row >= row_hi) row = row_hi - 1;          // clamp: loaded but weighted by zero below
       const char* rp = base + row * row_bytes;
 #pragma unroll
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) s += red[pb][r][w];
-      const int64_t row = row_lo + step * R + r;
+      const int64_t row = row_lo + first + step * group + r;
       if (row < row_hi) {
         if (b != nullptr) s -= b[row];
         rr += (double)s * (double)s;
@@ -198,13 +203,16 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
     }
   };
 
-  if (nsteps > 0) issue(0, 0);
-  for (int64_t s = 0; s < nsteps; s += 2) {
-    if (s + 1 < nsteps) issue(1, s + 1);
-    consume(0, s);
-    if (s + 1 < nsteps) {
-      if (s + 2 < nsteps) issue(0, s + 2);
-      consume(1, s + 1);
+#pragma unroll
+  for (int u = 0; u < NBUF - 1; ++u)
+    if (u < nsteps) issue(u, u);
+  for (int64_t s = 0; s < nsteps; s += NBUF) {
+#pragma unroll
+    for (int u = 0; u < NBUF; ++u) {
+      if (s + u < nsteps) {
+        if (s + u + NBUF - 1 < nsteps) issue((u + NBUF - 1) % NBUF, s + u + NBUF - 1);
+        consume(u, s + u);
+      }
     }
   }
 

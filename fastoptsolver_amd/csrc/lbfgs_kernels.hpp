@@ -19,76 +19,147 @@ namespace fos {
 constexpr int LB_THREADS = 1024;
 constexpr int LB_MAXHIST = 64;
 
-// workgroup-wide sum of two doubles; result broadcast to every thread
-__device__ inline void block_sum2_bcast(double& a, double& b, double* lds /* 2*16 + 2 */) {
+// Workgroup-wide sum of NV doubles, result broadcast to every thread.  Two barriers, no serial stage: every
+// thread adds the 16 wave partials itself (LDS broadcast reads), in the same fixed order -> deterministic.
+template <int NV>
+__device__ inline void block_sum_bcast(double (&v)[NV], double (*lds)[LB_THREADS / 64]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  a = wave_sum(a);
-  b = wave_sum(b);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
   __syncthreads();                       // previous readers of lds are done
-  if (lane == 0) { lds[wave] = a; lds[16 + wave] = b; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double sa = 0.0, sb = 0.0;
-    for (int i = 0; i < LB_THREADS / 64; ++i) { sa += lds[i]; sb += lds[16 + i]; }
-    lds[32] = sa; lds[33] = sb;
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) lds[i][wave] = v[i];
   }
   __syncthreads();
-  a = lds[32];
-  b = lds[33];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < LB_THREADS / 64; ++w) s += lds[i][w];
+    v[i] = s;
+  }
 }
 
+// NQ = float4 chunks of q per thread kept in REGISTERS (n <= NQ * 4096); NQ = 0: q lives in global memory
+// (any n; each thread only ever touches its own elements, so no cross-thread hazard on q).
+template <int NQ>
 __global__ __launch_bounds__(LB_THREADS) void lbfgs_two_loop_kernel(const float* __restrict__ g,
                                                                     const float* __restrict__ S,
                                                                     const float* __restrict__ Y, int hist, int head,
-                                                                    int cap, int64_t n, float* __restrict__ q) {
-  __shared__ double lds[34];
+                                                                    int cap, int64_t n, float* __restrict__ qout) {
+  __shared__ double lds[3][LB_THREADS / 64];
   __shared__ double coef[LB_MAXHIST];
   __shared__ double rho[LB_MAXHIST];
   const int tid = threadIdx.x;
-  for (int64_t i = tid; i < n; i += LB_THREADS) q[i] = g[i];
-  __syncthreads();
+  constexpr int NR = NQ > 0 ? NQ : 1;
+  f32x4 q[NR];
+  const bool vec_ok = (NQ > 0);
+  auto col_of = [&](int c) { return (int64_t)(c * LB_THREADS + tid) * 4; };
+  if constexpr (NQ > 0) {
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+      const int64_t col = col_of(c);
+      q[c] = col < n ? *reinterpret_cast<const f32x4*>(g + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  } else {
+    for (int64_t i = tid; i < n; i += LB_THREADS) qout[i] = g[i];
+  }
+  (void)vec_ok;
   double sy_last = 1.0, yy_last = 1.0;
   for (int h = hist - 1; h >= 0; --h) {
     const int slot = (head + h) % cap;
     const float* s = S + (int64_t)slot * n;
     const float* y = Y + (int64_t)slot * n;
-    double sq = 0.0, ys = 0.0, yy = 0.0;
-    for (int64_t i = tid; i < n; i += LB_THREADS) {
-      const double sv = s[i], yv = y[i];
-      sq += sv * (double)q[i];
-      ys += yv * sv;
-      if (h == hist - 1) yy += yv * yv;
+    double acc[3] = {0.0, 0.0, 0.0};          // s.q, y.s, y.y
+    f32x4 yk[NR];
+    if constexpr (NQ > 0) {
+#pragma unroll
+      for (int c = 0; c < NQ; ++c) {
+        const int64_t col = col_of(c);
+        f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+        yk[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (col < n) { sv = *reinterpret_cast<const f32x4*>(s + col); yk[c] = *reinterpret_cast<const f32x4*>(y + col); }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[0] += (double)sv[e] * (double)q[c][e];
+          acc[1] += (double)yk[c][e] * (double)sv[e];
+          acc[2] += (double)yk[c][e] * (double)yk[c][e];
+        }
+      }
+    } else {
+      for (int64_t i = tid; i < n; i += LB_THREADS) {
+        const double sv = s[i], yv = y[i];
+        acc[0] += sv * (double)qout[i];
+        acc[1] += yv * sv;
+        acc[2] += yv * yv;
+      }
     }
-    block_sum2_bcast(sq, ys, lds);
-    if (h == hist - 1) {
-      double dummy = 0.0;
-      block_sum2_bcast(yy, dummy, lds);
-      sy_last = ys;
-      yy_last = yy;
-    }
-    const double r = 1.0 / ys;
-    const double a = r * sq;
+    block_sum_bcast<3>(acc, lds);
+    if (h == hist - 1) { sy_last = acc[1]; yy_last = acc[2]; }
+    const double r = 1.0 / acc[1];
+    const double a = r * acc[0];
     if (tid == 0) { coef[h] = a; rho[h] = r; }
-    for (int64_t i = tid; i < n; i += LB_THREADS) q[i] = (float)((double)q[i] - a * (double)y[i]);
-    __syncthreads();
+    if constexpr (NQ > 0) {
+#pragma unroll
+      for (int c = 0; c < NQ; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[c][e] = (float)((double)q[c][e] - a * (double)yk[c][e]);
+    } else {
+      for (int64_t i = tid; i < n; i += LB_THREADS) qout[i] = (float)((double)qout[i] - a * (double)y[i]);
+    }
   }
+  __syncthreads();                            // coef / rho visible to everyone
   if (hist > 0) {
     const double gam = sy_last / yy_last;
-    for (int64_t i = tid; i < n; i += LB_THREADS) q[i] = (float)((double)q[i] * gam);
-    __syncthreads();
+    if constexpr (NQ > 0) {
+#pragma unroll
+      for (int c = 0; c < NQ; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[c][e] = (float)((double)q[c][e] * gam);
+    } else {
+      for (int64_t i = tid; i < n; i += LB_THREADS) qout[i] = (float)((double)qout[i] * gam);
+    }
   }
   for (int h = 0; h < hist; ++h) {
     const int slot = (head + h) % cap;
     const float* s = S + (int64_t)slot * n;
     const float* y = Y + (int64_t)slot * n;
-    double yq = 0.0, dummy = 0.0;
-    for (int64_t i = tid; i < n; i += LB_THREADS) yq += (double)y[i] * (double)q[i];
-    block_sum2_bcast(yq, dummy, lds);
-    const double w = coef[h] - rho[h] * yq;
-    for (int64_t i = tid; i < n; i += LB_THREADS) q[i] = (float)((double)q[i] + w * (double)s[i]);
-    __syncthreads();
+    double acc[1] = {0.0};
+    f32x4 sk[NR];
+    if constexpr (NQ > 0) {
+#pragma unroll
+      for (int c = 0; c < NQ; ++c) {
+        const int64_t col = col_of(c);
+        f32x4 yv = {0.f, 0.f, 0.f, 0.f};
+        sk[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (col < n) { yv = *reinterpret_cast<const f32x4*>(y + col); sk[c] = *reinterpret_cast<const f32x4*>(s + col); }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[0] += (double)yv[e] * (double)q[c][e];
+      }
+    } else {
+      for (int64_t i = tid; i < n; i += LB_THREADS) acc[0] += (double)y[i] * (double)qout[i];
+    }
+    block_sum_bcast<1>(acc, lds);
+    const double w = coef[h] - rho[h] * acc[0];
+    if constexpr (NQ > 0) {
+#pragma unroll
+      for (int c = 0; c < NQ; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[c][e] = (float)((double)q[c][e] + w * (double)sk[c][e]);
+    } else {
+      for (int64_t i = tid; i < n; i += LB_THREADS) qout[i] = (float)((double)qout[i] + w * (double)s[i]);
+    }
   }
-  for (int64_t i = tid; i < n; i += LB_THREADS) q[i] = -q[i];
+  if constexpr (NQ > 0) {
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+      const int64_t col = col_of(c);
+      if (col < n) *reinterpret_cast<f32x4*>(qout + col) = -q[c];
+    }
+  } else {
+    for (int64_t i = tid; i < n; i += LB_THREADS) qout[i] = -qout[i];
+  }
 }
 
 // out4 = { x.x, g.d, d.d, max|g| }; any pointer may be NULL (its entries are then 0).

@@ -224,12 +224,33 @@ __global__ __launch_bounds__(64) void fista_finalize_kernel(const double* __rest
                                                            const double* __restrict__ rr_part, int n_rr,
                                                            FistaScalars* __restrict__ scal, FistaParams prm) {
   if (scal->stopped != 0) return;
+  // issue every load before the first use: the partials were written by other CUs (L2 / MALL latency each)
   double s[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int i = threadIdx.x; i < nparts; i += 64) {
-    s[0] += part[i * 4 + 0]; s[1] += part[i * 4 + 1]; s[2] += part[i * 4 + 2]; s[3] += part[i * 4 + 3];
-  }
   double rr = 0.0;
-  for (int i = threadIdx.x; i < n_rr; i += 64) rr += rr_part[i];
+  constexpr int UNR = 4;
+  for (int base = 0; base < nparts; base += 64 * UNR) {
+    double v[UNR][4];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int i = base + u * 64 + threadIdx.x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[u][j] = i < nparts ? part[i * 4 + j] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] += v[u][j];
+  }
+  for (int base = 0; base < n_rr; base += 64 * UNR) {
+    double v[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int i = base + u * 64 + threadIdx.x;
+      v[u] = i < n_rr ? rr_part[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) rr += v[u];
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) s[i] = wave_sum(s[i]);
   rr = wave_sum(rr);

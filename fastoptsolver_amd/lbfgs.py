@@ -21,6 +21,8 @@ from .operators import vec_axpby
 
 _M, _FACTR, _MAXLS = 10, 1e7, 20
 _EPS = float(np.finfo(np.float64).eps)
+_EPS32 = float(np.finfo(np.float32).eps)
+_FLAT_TRIALS = 3     # consecutive trial points whose objective is indistinguishable from f(x_k) in float32
 
 
 class LBFGSSolver:
@@ -107,7 +109,7 @@ class LBFGSSolver:
             x_old, g_old, f_old = x, g, f
             ls = LineSearch()
             stp = ls.begin(stp, f_old, gd0)
-            evals, failed, gd1 = 0, False, gd0
+            evals, failed, gd1, flat = 0, False, gd0, 0
             while True:
                 if evals >= _MAXLS:
                     failed = True
@@ -119,6 +121,19 @@ class LBFGSSolver:
                 stp = ls.step(stp, f, gd1)
                 if ls.status != "FG":
                     break
+                # A pass over A in float32 resolves f only to ~eps32*|f|: once several trial points in a row
+                # are indistinguishable from f(x_k) the search cannot make progress (SURVEY §7 "L-BFGS in fp32").
+                flat = flat + 1 if abs(f - f_old) <= 4.0 * _EPS32 * max(abs(f_old), 1.0) else 0
+                if flat >= _FLAT_TRIALS:
+                    break
+            if flat >= _FLAT_TRIALS and ls.status == "FG":
+                if f <= f_old:
+                    nit += 1
+                    callback(x)
+                else:
+                    x, g, f = x_old, g_old, f_old
+                task = "CONVERGENCE: LINE SEARCH REACHED THE FLOAT32 RESOLUTION OF F"
+                break
             if failed or ls.status.startswith("ERROR"):
                 x, g, f = x_old, g_old, f_old
                 if hist == 0:

@@ -51,21 +51,31 @@ __global__ void reduce_slabs(const float* slabs, int nslabs, int n, float* g) {
 
 struct Variant {
   std::string name;
-  int threads, k, r;
-  void (*launch)(const float*, int64_t, const float*, int64_t, int, fos::YSource, int64_t, float*, double*, int, hipStream_t);
+  int threads, k, r, epc;
+  void (*launch)(const void*, int64_t, const float*, int64_t, int, fos::YSource, int64_t, float*, double*, int, hipStream_t);
 };
 
-template <int THREADS, int K, int R, bool NT, int MINW>
-void launch_variant(const float* A, int64_t lda, const float* b, int64_t m, int n, fos::YSource ys, int64_t rpw,
+template <typename T, int THREADS, int K, int R, bool NT, int MINW, int NBUF = 2, bool IL = false>
+void launch_variant(const void* A, int64_t lda, const float* b, int64_t m, int n, fos::YSource ys, int64_t rpw,
                     float* slabs, double* rr, int nwg, hipStream_t st) {
-  hipLaunchKernelGGL((fos::gemv_pair_kernel<float, THREADS, K, R, NT, MINW>), dim3(nwg), dim3(THREADS), 0, st, A, lda, b, m,
-                     n, ys, rpw, slabs, rr);
+  hipLaunchKernelGGL((fos::gemv_pair_kernel<T, THREADS, K, R, NT, MINW, true, NBUF, IL>), dim3(nwg), dim3(THREADS), 0, st,
+                     (const T*)A, lda, b, m, n, ys, rpw, slabs, rr);
+}
+
+__global__ void to_bf16(const float* in, unsigned short* out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    unsigned u = __float_as_uint(in[i]);
+    out[i] = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+  }
 }
 
 int main(int argc, char** argv) {
   int64_t m = argc > 1 ? atoll(argv[1]) : 65536;
   int n = argc > 2 ? atoi(argv[2]) : 8192;
   int iters = argc > 3 ? atoi(argv[3]) : 20;
+  const bool bf16 = argc > 4 && std::string(argv[4]) == "bf16";
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
   printf("device %s  CUs %d  m %lld n %d  A %.2f GiB\n", prop.name, prop.multiProcessorCount, (long long)m, n,
@@ -92,14 +102,28 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   fos::YSource ys{y, nullptr, nullptr, nullptr, nullptr};
+  unsigned short* A16 = nullptr;
+  if (bf16) {
+    CK(hipMalloc(&A16, (size_t)m * n * 2));
+    to_bf16<<<4096, 256, 0, st>>>(A, A16, (size_t)m * n);
+    CK(hipStreamSynchronize(st));
+  }
+  const void* Aany = bf16 ? (const void*)A16 : (const void*)A;
 
   // reference gradient via the two-pass fallback
   {
-    hipLaunchKernelGGL(fos::residual_rows_kernel<float>, dim3(2048), dim3(256), 0, st, A, (int64_t)n, b, m, n, ys, rvec, rr);
     int chunks = 64;
     int64_t rpc = (m + chunks - 1) / chunks;
-    hipLaunchKernelGGL(fos::transpose_rows_kernel<float>, dim3((n + 255) / 256, chunks), dim3(256), 0, st, A, (int64_t)n, m,
-                       n, rvec, (const int*)nullptr, rpc, slabs);
+    if (bf16) {
+      hipLaunchKernelGGL(fos::residual_rows_kernel<fos::bf16_t>, dim3(2048), dim3(256), 0, st, (const fos::bf16_t*)A16,
+                         (int64_t)n, b, m, n, ys, rvec, rr);
+      hipLaunchKernelGGL(fos::transpose_rows_kernel<fos::bf16_t>, dim3((n + 255) / 256, chunks), dim3(256), 0, st,
+                         (const fos::bf16_t*)A16, (int64_t)n, m, n, rvec, (const int*)nullptr, rpc, slabs);
+    } else {
+      hipLaunchKernelGGL(fos::residual_rows_kernel<float>, dim3(2048), dim3(256), 0, st, A, (int64_t)n, b, m, n, ys, rvec, rr);
+      hipLaunchKernelGGL(fos::transpose_rows_kernel<float>, dim3((n + 255) / 256, chunks), dim3(256), 0, st, A, (int64_t)n, m,
+                         n, rvec, (const int*)nullptr, rpc, slabs);
+    }
     reduce_slabs<<<(n + 255) / 256, 256, 0, st>>>(slabs, chunks, n, gref);
     CK(hipStreamSynchronize(st));
   }
@@ -109,7 +133,7 @@ int main(int argc, char** argv) {
   for (float v : href) refnorm += (double)v * v;
   refnorm = std::sqrt(refnorm);
 
-  const double bytes = (double)m * n * 4;
+  const double bytes = (double)m * n * (bf16 ? 2 : 4);
   // stream ceiling
   for (int nt = 0; nt < 2; ++nt) {
     for (int rep = 0; rep < 2; ++rep) {
@@ -127,8 +151,23 @@ int main(int argc, char** argv) {
   }
 
   std::vector<Variant> vs;
-#define V(T_, K_, R_, NT_, W_) vs.push_back({"t" #T_ "_k" #K_ "_r" #R_ "_nt" #NT_ "_w" #W_, T_, K_, R_, launch_variant<T_, K_, R_, NT_, W_>})
-  if (n <= 8192) {
+#define V(T_, K_, R_, NT_, W_) vs.push_back({"t" #T_ "_k" #K_ "_r" #R_ "_nt" #NT_ "_w" #W_, T_, K_, R_, 4, launch_variant<float, T_, K_, R_, NT_, W_>})
+#define VB(T_, K_, R_, NT_, W_) vs.push_back({"bf16_t" #T_ "_k" #K_ "_r" #R_ "_nt" #NT_ "_w" #W_, T_, K_, R_, 8, launch_variant<fos::bf16_t, T_, K_, R_, NT_, W_>})
+#define VX(T_, K_, R_, W_, NB_, IL_) vs.push_back({"t" #T_ "_k" #K_ "_r" #R_ "_nbuf" #NB_ "_il" #IL_, T_, K_, R_, 4, launch_variant<float, T_, K_, R_, true, W_, NB_, IL_>})
+  if (!bf16 && argc > 5) {
+    // experiment set: deeper prefetch / interleaved rows
+    if (n <= 8192) {
+      VX(512, 4, 2, 2, 2, false); VX(512, 4, 2, 2, 3, false); VX(512, 4, 2, 2, 4, false); VX(512, 4, 1, 2, 4, false);
+      VX(512, 4, 2, 2, 2, true); VX(512, 4, 2, 2, 3, true); VX(512, 4, 1, 2, 3, true); VX(1024, 2, 2, 4, 3, false);
+      VX(1024, 2, 2, 4, 2, true); VX(256, 8, 1, 2, 3, false); VX(512, 4, 1, 2, 2, true);
+    } else {
+      VX(512, 8, 1, 2, 2, false); VX(512, 8, 1, 2, 3, false); VX(512, 8, 1, 2, 2, true); VX(1024, 4, 1, 4, 2, true);
+      VX(1024, 4, 1, 4, 3, false);
+    }
+  } else if (bf16) {
+    if (n <= 8192) { VB(256, 4, 2, true, 2); VB(512, 2, 2, true, 2); VB(512, 2, 4, true, 2); VB(1024, 1, 4, true, 4); VB(1024, 1, 2, true, 4); }
+    else { VB(512, 4, 2, true, 2); VB(512, 4, 1, true, 2); VB(512, 4, 1, true, 4); VB(1024, 2, 2, true, 4); VB(1024, 2, 1, true, 4); VB(1024, 2, 4, true, 4); VB(512, 4, 2, false, 2); }
+  } else if (n <= 8192) {
     V(256, 8, 1, false, 2); V(256, 8, 2, false, 2); V(256, 8, 2, true, 2); V(256, 8, 1, true, 3); V(256, 8, 1, true, 4);
     V(512, 4, 2, true, 2); V(512, 4, 2, true, 4); V(512, 4, 4, true, 2); V(512, 4, 4, false, 2); V(512, 4, 1, true, 4);
     V(1024, 2, 4, true, 4); V(1024, 2, 2, true, 4); V(1024, 2, 4, false, 4); V(1024, 2, 1, true, 4);
@@ -138,16 +177,16 @@ int main(int argc, char** argv) {
   }
 
   // workgroups per CU to try
-  const int wpc_list[] = {1, 2, 3, 4, 6, 8};
+  const int wpc_list[] = {1, 2, 4};
   for (auto& v : vs) {
-    if ((int64_t)v.threads * v.k * 4 < n) continue;
+    if ((int64_t)v.threads * v.k * v.epc < n) continue;
     for (int wpc : wpc_list) {
       if (wpc * v.threads > 2048) continue;
       int nwg = ncu * wpc;
       if (nwg > max_wg) continue;
       int64_t rpw = (m + nwg - 1) / nwg;
       // correctness
-      v.launch(A, n, b, m, n, ys, rpw, slabs, rr, nwg, st);
+      v.launch(Aany, n, b, m, n, ys, rpw, slabs, rr, nwg, st);
       reduce_slabs<<<(n + 255) / 256, 256, 0, st>>>(slabs, nwg, n, g);
       if (hipStreamSynchronize(st) != hipSuccess) { printf("%s wpc %d LAUNCH FAILED\n", v.name.c_str(), wpc); (void)hipGetLastError(); continue; }
       CK(hipMemcpy(hg.data(), g, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -157,7 +196,7 @@ int main(int argc, char** argv) {
       float best = 1e30f, tot = 0;
       for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0, st));
-        for (int i = 0; i < iters; ++i) v.launch(A, n, b, m, n, ys, rpw, slabs, rr, nwg, st);
+        for (int i = 0; i < iters; ++i) v.launch(Aany, n, b, m, n, ys, rpw, slabs, rr, nwg, st);
         CK(hipEventRecord(e1, st));
         CK(hipEventSynchronize(e1));
         float ms;
