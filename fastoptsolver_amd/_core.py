@@ -76,7 +76,7 @@ class Problem:
         if self.b is not None and self.b.numel() != self.m:
             raise ValueError("b must have m entries")
         self.gbuf = torch.zeros(self.n + 4, dtype=torch.float32, device=self.device)
-        self.scratch = torch.zeros(16, dtype=torch.float64, device=self.device)
+        self.scratch = torch.zeros(32, dtype=torch.float64, device=self.device)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(lib.fos_problem_create(C.byref(h), ptr(self.A), self.m, self.n, self.lda,
@@ -132,6 +132,17 @@ class Problem:
             _lib.check(self.lib.fos_residual_objective(self.h, ptr(x), ptr(self.scratch)), "fos_residual_objective")
         v = self.scratch[:3].cpu()
         return float(v[0]), float(v[1]), float(v[2])
+
+    def residual_batch(self, X, use_b=True):
+        """||A X_j - b||^2 for the <= 16 columns of X (n x nv) in one MFMA pass; host list.  Synchronises."""
+        X = torch.as_tensor(X, device=self.device, dtype=torch.float32)
+        nv = X.shape[1]
+        Xf = torch.zeros(self.n, 16, dtype=torch.float32, device=self.device)
+        Xf[:, :nv] = X
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fos_residual_batch(self.h, ptr(Xf), nv, int(bool(use_b)), ptr(self.scratch)),
+                       "fos_residual_batch")
+        return self.scratch[:nv].cpu().tolist()
 
     def power_iter(self, v0, n_iter=100, tol=1e-6):
         v = to_device_vec(v0, self.device).clone()
@@ -207,6 +218,18 @@ class Fista:
             _lib.check(self.lib.fos_fista_trial(self.h, float(t), int(bool(with_residual)), out), "fos_fista_trial")
         keys = ("gd", "dd", "nnz", "gnorm2", "y2", "q", "rr_y")
         return dict(zip(keys, list(out)))
+
+    def trial_batch(self, t, eta, nv=16):
+        """Candidates t*eta^j, j < nv, decided by one MFMA pass over A; list of dicts like trial().  None when the
+        problem runs the two-pass fallback."""
+        out = (C.c_double * (8 * nv))()
+        with torch.cuda.device(self.prob.device):
+            rc = self.lib.fos_fista_trial_batch(self.h, float(t), float(eta), int(nv), out)
+        if rc == -4:
+            return None
+        _lib.check(rc, "fos_fista_trial_batch")
+        keys = ("gd", "dd", "nnz", "gnorm2", "y2", "q", "rr_y")
+        return [dict(zip(keys, out[8 * j: 8 * j + 7])) for j in range(nv)]
 
     def status(self):
         st = _lib.FistaStatus()

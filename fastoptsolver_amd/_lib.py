@@ -41,6 +41,7 @@ SIGNATURES = {
     "fos_problem_profile_read": (_i32, [_vp, C.POINTER(_f64), C.POINTER(_i64)]),
     "fos_gemv_pair": (_i32, [_vp, _vp, _f32, _vp, _vp]),
     "fos_residual_objective": (_i32, [_vp, _vp, _vp]),
+    "fos_residual_batch": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "fos_power_iter": (_i32, [_vp, _vp, _i32, _f64, C.POINTER(_f64), C.POINTER(_i32)]),
     "fos_prox_l1": (_i32, [_vp, _f32, _vp, _i64, _vp]),
     "fos_prox_elastic_net": (_i32, [_vp, _f32, _f32, _f32, _vp, _i64, _vp]),
@@ -52,6 +53,7 @@ SIGNATURES = {
     "fos_fista_grad": (_i32, [_vp]),
     "fos_fista_update": (_i32, [_vp]),
     "fos_fista_trial": (_i32, [_vp, _f64, _i32, C.POINTER(_f64)]),   # out8
+    "fos_fista_trial_batch": (_i32, [_vp, _f64, _f64, _i32, C.POINTER(_f64)]),
     "fos_fista_status_get": (_i32, [_vp, C.POINTER(FistaStatus)]),
     "fos_fista_get_x": (_i32, [_vp, _vp]),
     "fos_fista_x": (_vp, [_vp]),

@@ -1,0 +1,187 @@
+// Batched Armijo trials: ||A dlt_j||^2 for up to 16 candidate steps in ONE pass over A, on the matrix cores.
+//
+// Spec: the backtracking loops iterative_solvers.py:187-194 / :302-309 / :96-104 evaluate g at one candidate per
+// trial (two passes over A each).  With dlt_j = prox(y - t_j*grad) - y for t_j = t*eta^j, j = 0..NV-1, the test of
+// candidate j is (1-C)*grad.dlt_j + 0.5*||A dlt_j||^2 + 0.5*alpha2*||dlt_j||^2 <= 0, so ONE kernel that
+// returns q_j = ||A dlt_j||^2 for all j decides the whole line search.  SURVEY.md §8(f) rank 1.
+//
+// This is GEMM-shaped (A[m x n] times X[n x 16]), so it runs on MFMA: v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered
+// fma chain).  Per 64-row x 64-column tile the workgroup stages A through LDS with fully coalesced 16-byte loads
+// (4 rows x 256 B per wave instruction); a fragment-shaped direct load would touch 16 rows x 64 B per instruction.
+// Wave w owns rows 16w..16w+15 of the tile: lane l supplies A[row l&15][col 4(l>>4)+c] (one ds_read_b128, c = the
+// four MFMA steps) and X[col 4(l>>4)+c][vector l&15] (one ds_read_b128 of the pre-permuted candidate block).
+// D (4 VGPRs) holds 16 rows x 16 candidates.  Rate: 64 MFMAs of 32 cycles per 16 KiB tile per CU = 32 B/clk/CU of
+// matrix-core capacity against the ~13 B/clk/CU the HBM stream delivers (~40 % MFMA busy) - with 16 right-hand
+// sides the matrix cores are the right unit; with one (the main gradient kernel) they are not.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gemv_pair.hpp"
+#include "reduce_update.hpp"
+
+namespace fos {
+
+constexpr int BT_NV = 16;            // candidates per pass (MFMA N)
+constexpr int BT_ROWS = 64;          // rows per tile  (4 waves x 16)
+constexpr int BT_COLS = 64;          // columns per tile
+constexpr int BT_LDS_STRIDE = BT_COLS + 4;   // padded row stride (floats): rows land on distinct bank groups
+constexpr int BT_THREADS = 256;
+constexpr int BT_W = 3 * BT_NV + 2;  // per-workgroup outputs of the candidate kernel
+
+// X block layout ("Xp"): for column k and candidate j,
+//   Xp[ ((k/16)*4 + (k%16)/4) * 64 + j*4 + (k%4) ]
+// i.e. per 16-column subtile a [q = 4][j = 16][c = 4] cube: the float4 a lane needs for one subtile is contiguous and
+// the 64 lanes of a wave read 1 KiB contiguous.
+__device__ __host__ inline int64_t xp_index(int64_t k, int j) {
+  return ((k / 16) * 4 + (k % 16) / 4) * 64 + (int64_t)j * 4 + (k % 4);
+}
+
+// Candidate generation: dlt_j (fp64 -> fp32, written in Xp layout) and per-candidate sums.
+// part[wg] = { gd_j (16), dd_j (16), nnz_j (16), ||grad||^2, ||y||^2 }.
+__global__ __launch_bounds__(256) void fista_trial_batch_kernel(const float* __restrict__ gbuf, int n, int n_pad,
+                                                               const double* __restrict__ x_cur,
+                                                               const double* __restrict__ x_prev,
+                                                               const FistaScalars* __restrict__ scal, FistaParams prm,
+                                                               double t0, double eta, int nv, float* __restrict__ xp,
+                                                               double* __restrict__ part) {
+  __shared__ double red[4][BT_W];
+  const double beta = scal->beta;
+  double gd[BT_NV], dd[BT_NV], nz[BT_NV];
+#pragma unroll
+  for (int j = 0; j < BT_NV; ++j) { gd[j] = 0.0; dd[j] = 0.0; nz[j] = 0.0; }
+  double g2 = 0.0, y2 = 0.0;
+  for (int col = blockIdx.x * 256 + threadIdx.x; col < n_pad; col += gridDim.x * 256) {
+    if (col < n) {
+      const double y = form_y(x_cur[col], x_prev[col], beta);
+      double gf = (double)gbuf[col];
+      if (prm.prox_kind == PROX_L1 && prm.alpha2 > 0.0) gf += prm.alpha2 * y;
+      g2 += gf * gf;
+      y2 += y * y;
+      double t = t0;
+#pragma unroll
+      for (int j = 0; j < BT_NV; ++j) {
+        double d = 0.0;
+        if (j < nv) {
+          const double v = y - t * gf;
+          double xt = prm.alpha1 > 0.0 ? soft_threshold(v, t * prm.alpha1) : v;
+          if (prm.prox_kind == PROX_ENET) xt *= 1.0 / (1.0 + t * prm.alpha2);
+          d = xt - y;
+          gd[j] += gf * d;
+          dd[j] += d * d;
+          nz[j] += (d != 0.0) ? 1.0 : 0.0;
+        }
+        xp[xp_index(col, j)] = (float)d;
+        t *= eta;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < BT_NV; ++j) xp[xp_index(col, j)] = 0.f;     // zero padding up to a multiple of 64 columns
+    }
+  }
+  // block reduction of the BT_W values: wave butterflies, one LDS exchange, one barrier
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto put = [&](double v, int slot) {
+    v = wave_sum(v);
+    if (lane == 0) red[wave][slot] = v;
+  };
+#pragma unroll
+  for (int j = 0; j < BT_NV; ++j) { put(gd[j], j); put(dd[j], BT_NV + j); put(nz[j], 2 * BT_NV + j); }
+  put(g2, 3 * BT_NV);
+  put(y2, 3 * BT_NV + 1);
+  __syncthreads();
+  if (threadIdx.x < BT_W)
+    part[(int64_t)blockIdx.x * BT_W + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// q_part[wg][j] = sum over this workgroup's rows of (A_i . X_j - use_b * b_i)^2.
+// Requirements (host-checked): n % 4 == 0, lda % 4 == 0, A 16-byte aligned, Xp zero-padded to n_pad = 64*ceil(n/64).
+__global__ __launch_bounds__(BT_THREADS, 2) void residual_batch_mfma_kernel(const float* __restrict__ A, int64_t lda,
+                                                                           const float* __restrict__ b, int use_b,
+                                                                           int64_t m, int n,
+                                                                           const float* __restrict__ xp,
+                                                                           int64_t groups_per_wg,
+                                                                           double* __restrict__ q_part) {
+  __shared__ __attribute__((aligned(16))) float a_s[2][BT_ROWS][BT_LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float x_s[2][BT_COLS * BT_NV];
+  __shared__ double wsum[4][BT_NV];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t ngroups = (m + BT_ROWS - 1) / BT_ROWS;
+  const int64_t g_lo = (int64_t)blockIdx.x * groups_per_wg;
+  int64_t g_hi = g_lo + groups_per_wg;
+  if (g_hi > ngroups) g_hi = ngroups;
+  const int ktiles = (n + BT_COLS - 1) / BT_COLS;
+  const int64_t ntiles = (g_hi > g_lo ? (g_hi - g_lo) : 0) * ktiles;
+
+  f32x4 areg[4];
+  f32x4 xreg;
+  auto load_tile = [&](int64_t t) {
+    const int64_t grp = g_lo + t / ktiles;
+    const int kt = (int)(t % ktiles);
+    const int64_t row0 = grp * BT_ROWS;
+    const int col0 = kt * BT_COLS;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f = u * BT_THREADS + tid;
+      int64_t row = row0 + f / 16;
+      int col = col0 + 4 * (f % 16);
+      if (row >= m) row = m - 1;                 // clamped rows are masked when the residual is formed
+      if (col >= n) col = n - 4;                 // clamped columns meet zero rows of Xp
+      areg[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A + row * lda + col));
+    }
+    xreg = *reinterpret_cast<const f32x4*>(xp + (int64_t)kt * (BT_COLS * BT_NV) + 4 * tid);
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f = u * BT_THREADS + tid;
+      *reinterpret_cast<f32x4*>(&a_s[buf][f / 16][4 * (f % 16)]) = areg[u];
+    }
+    *reinterpret_cast<f32x4*>(&x_s[buf][4 * tid]) = xreg;
+  };
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  double qsum = 0.0;                              // this lane's candidate j = lane & 15, its 4 rows
+  if (ntiles > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int64_t t = 0; t < ntiles; ++t) {
+    const int buf = (int)(t & 1);
+    if (t + 1 < ntiles) load_tile(t + 1);         // global loads in flight behind the MFMAs
+#pragma unroll
+    for (int sub = 0; sub < BT_COLS / 16; ++sub) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(&a_s[buf][16 * wave + (lane & 15)][16 * sub + 4 * (lane >> 4)]);
+      const f32x4 x4 = *reinterpret_cast<const f32x4*>(&x_s[buf][(sub * 4 + (lane >> 4)) * 64 + (lane & 15) * 4]);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, x4.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, x4.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, x4.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, x4.w, acc, 0, 0, 0);
+    }
+    if ((t + 1) % ktiles == 0) {
+      // row group complete: D[row = 4*(lane>>4)+reg][candidate = lane&15]
+      const int64_t row0 = (g_lo + t / ktiles) * BT_ROWS + 16 * wave + 4 * (lane >> 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = row0 + r;
+        if (row < m) {
+          float v = acc[r];
+          if (use_b) v -= b[row];
+          qsum += (double)v * (double)v;
+        }
+      }
+      acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (t + 1 < ntiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  // lanes j, j+16, j+32, j+48 hold candidate j
+  qsum += __shfl_xor(qsum, 16, 64);
+  qsum += __shfl_xor(qsum, 32, 64);
+  if (lane < BT_NV) wsum[wave][lane] = qsum;
+  __syncthreads();
+  if (tid < BT_NV) q_part[(int64_t)blockIdx.x * BT_NV + tid] = (wsum[0][tid] + wsum[1][tid]) + (wsum[2][tid] + wsum[3][tid]);
+}
+
+}  // namespace fos

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/fos.h"
+#include "batch_trial.hpp"
 #include "gemv_pair.hpp"
 #include "lbfgs_kernels.hpp"
 #include "reduce_update.hpp"
@@ -111,6 +112,11 @@ struct fos_problem {
   double* dscal = nullptr;           // 128 device doubles (scalars, power-iteration history)
   double* part = nullptr;            // partial sums of the small kernels
   int part_cap = 0;
+  // batched (MFMA) residual: permuted candidate block, per-workgroup partials, folded results
+  float* xp = nullptr;
+  double* q_part = nullptr;
+  double* bt_out = nullptr;          // 128 doubles
+  int64_t n_pad = 0;
   // optional kernel timing (fos_problem_profile)
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;   // pairs: [2i] start, [2i+1] stop
@@ -252,6 +258,39 @@ int launch_slab_reduce(fos_problem* p, int n_rr, float* gbuf, double* rr_out, co
   return FOS_OK;
 }
 
+__global__ void xp_pack_kernel(const float* __restrict__ X, int n, int n_pad, int nv, float* __restrict__ xp) {
+  for (int col = blockIdx.x * 256 + threadIdx.x; col < n_pad; col += gridDim.x * 256)
+    for (int j = 0; j < fos::BT_NV; ++j) xp[fos::xp_index(col, j)] = (col < n && j < nv) ? X[(int64_t)col * fos::BT_NV + j] : 0.f;
+}
+
+int ensure_batch_workspace(fos_problem* p) {
+  if (p->xp) return FOS_OK;
+  p->n_pad = (p->n + fos::BT_COLS - 1) / fos::BT_COLS * fos::BT_COLS;
+  HIP_TRY(hipMalloc(&p->xp, (size_t)p->n_pad * fos::BT_NV * sizeof(float)));
+  HIP_TRY(hipMalloc(&p->q_part, (size_t)(3 * p->ncu + 8) * fos::BT_NV * sizeof(double)));
+  HIP_TRY(hipMalloc(&p->bt_out, 128 * sizeof(double)));
+  return FOS_OK;
+}
+
+// q[j] = ||A Xp_j - use_b*b||^2 -> out16 (device); Xp already in p->xp.
+int launch_residual_batch(fos_problem* p, int use_b, double* out16) {
+  const int64_t ngroups = (p->m + fos::BT_ROWS - 1) / fos::BT_ROWS;
+  int64_t nwg = std::min<int64_t>(ngroups, 3 * (int64_t)p->ncu);
+  const int64_t gpw = (ngroups + nwg - 1) / nwg;
+  nwg = (ngroups + gpw - 1) / gpw;
+  int rc = prof_mark(p, true);
+  if (rc) return rc;
+  hipLaunchKernelGGL(fos::residual_batch_mfma_kernel, dim3((unsigned)nwg), dim3(fos::BT_THREADS), 0, p->stream,
+                     (const float*)p->A, p->lda, p->b, (use_b && p->b) ? 1 : 0, p->m, (int)p->n, p->xp, gpw, p->q_part);
+  LAUNCH_CHECK();
+  if ((rc = prof_mark(p, false))) return rc;
+  hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->q_part, (int)nwg, fos::BT_NV, out16);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
+bool batch_supported(const fos_problem* p) { return p->path == 0 && p->dtype == FOS_F32; }
+
 // A caller vector the fused prologue can read with 16-byte loads.
 int aligned_vec(fos_problem* p, const float* v, const float** out) {
   if ((reinterpret_cast<uintptr_t>(v) & 15u) == 0) {
@@ -328,7 +367,7 @@ int fos_problem_profile_read(fos_problem* p, double* ms_total, int64_t* launches
 int fos_problem_destroy(fos_problem* p) {
   if (!p) return FOS_OK;
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
-  void* bufs[] = {p->slabs, p->rr_part, p->rvec, p->gbuf_own, p->ybuf, p->dscal, p->part};
+  void* bufs[] = {p->slabs, p->rr_part, p->rvec, p->gbuf_own, p->ybuf, p->dscal, p->part, p->xp, p->q_part, p->bt_out};
   for (void* q : bufs)
     if (q) (void)hipFree(q);
   delete p;
@@ -388,10 +427,21 @@ int fos_residual_objective(fos_problem* p, const float* x, double* out3) {
   YSource ys{xa, nullptr, nullptr, nullptr, nullptr};
   int n_rr = 0;
   if ((rc = launch_pass(p, ys, p->b, false, &n_rr))) return rc;
-  hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(64), 0, p->stream, p->rr_part, n_rr, 1, out3);
+  hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->rr_part, n_rr, 1, out3);
   hipLaunchKernelGGL(fos::vec_norms_kernel, dim3(1), dim3(fos::LB_THREADS), 0, p->stream, xa, p->n, out3 + 1);
   LAUNCH_CHECK();
   return FOS_OK;
+}
+
+int fos_residual_batch(fos_problem* p, const float* X, int nv, int use_b, double* out16) {
+  if (!p || !X || !out16 || nv < 1 || nv > fos::BT_NV) return fail(FOS_ERR_ARG, "fos_residual_batch: bad argument");
+  if (!batch_supported(p)) return fail(FOS_ERR_UNSUPPORTED, "fos_residual_batch: needs the fused fp32 path");
+  int rc = ensure_batch_workspace(p);
+  if (rc) return rc;
+  hipLaunchKernelGGL(xp_pack_kernel, dim3(grid_1d(p->n_pad, 256, 256)), dim3(256), 0, p->stream, X, (int)p->n,
+                     (int)p->n_pad, nv, p->xp);
+  LAUNCH_CHECK();
+  return launch_residual_batch(p, use_b, out16);
 }
 
 int fos_power_iter(fos_problem* p, float* v_inout, int n_iter, double tol, double* L_out, int* iters_out) {
@@ -572,7 +622,7 @@ int fos_fista_trial(fos_fista* f, double t, int with_residual, double out8[8]) {
   HIP_TRY(hipMemsetAsync(f->out5, 0, 8 * sizeof(double), p->stream));
   hipLaunchKernelGGL(fos::fista_trial_kernel, dim3(grid), dim3(256), 0, p->stream, p->gbuf, (int)p->n, f->x_cur,
                      f->x_prev, f->scal, f->prm, t, f->dlt, p->part);
-  hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(64), 0, p->stream, p->part, grid, fos::TRIAL_W, f->out5);
+  hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->part, grid, fos::TRIAL_W, f->out5);
   LAUNCH_CHECK();
   // rr(y_k) was produced by fos_fista_grad; copy it before the trial pass reuses the partial buffer
   HIP_TRY(hipMemcpyAsync(f->out5 + 6, &f->scal->rr, sizeof(double), hipMemcpyDeviceToDevice, p->stream));
@@ -580,11 +630,42 @@ int fos_fista_trial(fos_fista* f, double t, int with_residual, double out8[8]) {
     YSource ys{f->dlt, nullptr, nullptr, nullptr, nullptr};
     int n_rr = 0, rc;
     if ((rc = launch_pass(p, ys, nullptr, false, &n_rr))) return rc;        // ||A dlt||^2  (b = 0)
-    hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(64), 0, p->stream, p->rr_part, n_rr, 1, f->out5 + 5);
+    hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->rr_part, n_rr, 1, f->out5 + 5);
     LAUNCH_CHECK();
   }
   HIP_TRY(hipMemcpyAsync(out8, f->out5, 8 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
+  return FOS_OK;
+}
+
+int fos_fista_trial_batch(fos_fista* f, double t, double eta, int nv, double* out) {
+  if (!f || !out || !(t > 0.0) || !(eta > 0.0) || nv < 1 || nv > fos::BT_NV)
+    return fail(FOS_ERR_ARG, "fos_fista_trial_batch: bad argument");
+  fos_problem* p = f->p;
+  if (!batch_supported(p)) return fail(FOS_ERR_UNSUPPORTED, "fos_fista_trial_batch: needs the fused fp32 path");
+  int rc = ensure_batch_workspace(p);
+  if (rc) return rc;
+  const int grid = grid_1d(p->n_pad, 256, 64);
+  hipLaunchKernelGGL(fos::fista_trial_batch_kernel, dim3(grid), dim3(256), 0, p->stream, p->gbuf, (int)p->n,
+                     (int)p->n_pad, f->x_cur, f->x_prev, f->scal, f->prm, t, eta, nv, p->xp, p->part);
+  hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->part, grid, fos::BT_W, p->bt_out);
+  LAUNCH_CHECK();
+  HIP_TRY(hipMemcpyAsync(p->bt_out + 100, &f->scal->rr, sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  if ((rc = launch_residual_batch(p, 0, p->bt_out + 64))) return rc;
+  double h[128];
+  HIP_TRY(hipMemcpyAsync(h, p->bt_out, 128 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  for (int j = 0; j < nv; ++j) {
+    double* o = out + 8 * j;
+    o[0] = h[j];                        // grad . dlt_j
+    o[1] = h[fos::BT_NV + j];           // ||dlt_j||^2
+    o[2] = h[2 * fos::BT_NV + j];       // #(dlt_j != 0)
+    o[3] = h[3 * fos::BT_NV];           // ||grad||^2
+    o[4] = h[3 * fos::BT_NV + 1];       // ||y||^2
+    o[5] = h[64 + j];                   // ||A dlt_j||^2
+    o[6] = h[100];                      // ||A y - b||^2
+    o[7] = 0.0;
+  }
   return FOS_OK;
 }
 

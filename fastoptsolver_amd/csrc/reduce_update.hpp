@@ -334,14 +334,17 @@ __global__ __launch_bounds__(256) void fista_trial_kernel(const float* __restric
   }
 }
 
-// Fold `nparts` rows of `width` doubles (fixed order) into out[width].  One wave.
-__global__ __launch_bounds__(64) void fold_partials_kernel(const double* __restrict__ part, int nparts, int width,
-                                                          double* __restrict__ out) {
-  for (int w = 0; w < width; ++w) {
+// Fold `nparts` rows of `width` doubles (fixed order) into out[width].  One workgroup of 16 waves: wave v folds
+// the columns v, v+16, ... (lanes stride over the rows, butterfly at the end) - deterministic.
+constexpr int FOLD_THREADS = 1024;
+__global__ __launch_bounds__(FOLD_THREADS) void fold_partials_kernel(const double* __restrict__ part, int nparts,
+                                                                    int width, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int w = wave; w < width; w += FOLD_THREADS / 64) {
     double s = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += 64) s += part[i * width + w];
+    for (int i = lane; i < nparts; i += 64) s += part[(int64_t)i * width + w];
     s = wave_sum(s);
-    if (threadIdx.x == 0) out[w] = s;
+    if (lane == 0) out[w] = s;
   }
 }
 

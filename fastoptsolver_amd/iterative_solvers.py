@@ -91,11 +91,33 @@ def estimate_lipschitz(A, n_iter: int = 100, tol: float = 1e-6) -> float:
 
 
 # ---------------------------------------------------------------------
+# Armijo acceptance (ref:191, :306, :101) in cancellation-free form
+# ---------------------------------------------------------------------
+_BATCH = 16      # candidate steps decided per pass over A (MFMA N dimension)
+
+
+def _armijo_accepts(tr, t_k, smooth_a2):
+    """g(x_tmp) <= g(y) + C*grad.dlt  <=>  (1-C)*grad.dlt + 0.5||A dlt||^2 + 0.5*a2*||dlt||^2 <= 0  (g quadratic).
+
+    Resolution of the test: (a) the reference compares two float64 evaluations of g, so differences below
+    eps64*g(y) read as "equal" there (and x_tmp == y ends its loop); (b) our gradient comes from an fp32 pass over
+    A, so grad.dlt is only known to ~eps32*||grad||*||dlt||; (c) a trial step shorter than t*eps32*||grad|| lies
+    inside the noise ball of y_k: its direction is rounding noise, the decision meaningless and the step harmless
+    - the fp32-gradient counterpart of the reference's exact "x_tmp == y" exit."""
+    excess = (1.0 - C) * tr["gd"] + 0.5 * tr["q"] + 0.5 * smooth_a2 * tr["dd"]
+    g_y = 0.5 * tr["rr_y"] + 0.5 * smooth_a2 * tr["y2"]
+    noise = max(_EPS64 * g_y, 8.0 * _EPS32 * math.sqrt(tr["gnorm2"] * tr["dd"]))
+    in_noise_ball = tr["dd"] <= (8.0 * _EPS32 * t_k) ** 2 * tr["gnorm2"]
+    return tr["nnz"] == 0 or excess <= noise or in_noise_ball
+
+
+# ---------------------------------------------------------------------
 # shared FISTA / FISTA-Δ / fused-ISTA driver
 # ---------------------------------------------------------------------
 def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backtracking=False, eta=0.5,
            max_iter=500, tol=0.0, tol_ratio=0.0, adaptive_restart=False, restart_threshold=1.0,
-           grad_tol_check=False, history=None, history_obj=None, x0=None, check_every=None, log=None):
+           grad_tol_check=False, history=None, history_obj=None, x0=None, check_every=None, log=None,
+           batch_trials=True):
     """Run the state machine.  Device-driven when nothing needs a per-iteration host decision,
     host-driven otherwise (grad-norm stop ref:179, backtracking ref:183-197, history ref:224-232)."""
     st = _core.Fista(prob)
@@ -106,6 +128,7 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
     gtimer = _EventTimer(grad_call_times)
     host_driven = backtracking or history is not None or log is not None or (grad_tol_check and tol > 0.0)
     smooth_a2 = alpha2 if (prox_kind == _lib.PROX_L1 and alpha2 > 0) else 0.0
+    use_batch = batch_trials
 
     if not host_driven:
         stops_possible = tol > 0.0 or tol_ratio > 0.0
@@ -137,25 +160,20 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
             bt_steps = 0
             ls_t0 = time.perf_counter()
             t_k = tau
-            while True:
-                # g(x_tmp) - g(y) - C*grad.dlt, evaluated without cancellation (g is quadratic; fos.h).
-                tr = st.trial(t_k, with_residual=True)
-                excess = (1.0 - C) * tr["gd"] + 0.5 * tr["q"] + 0.5 * smooth_a2 * tr["dd"]
-                # Resolution of this test: (a) the reference compares two float64 evaluations of g, so
-                # differences below eps64*g(y) read as "equal" there (and x_tmp == y ends its loop);
-                # (b) our gradient comes from an fp32 pass over A, so grad.dlt is only known to
-                # ~eps32*||grad||*||dlt|| (Cauchy-Schwarz bound times the rounding level) - at a converged
-                # fixed point dlt is pure gradient noise and must not trigger a step collapse.
-                # (c) a trial step shorter than t*||delta grad|| ~ t*eps32*||grad|| lies inside the noise ball of
-                # y_k: its direction is rounding noise, the decision is meaningless and the step harmless -
-                # this is the fp32-gradient counterpart of the reference's exact "x_tmp == y" exit.
-                g_y = 0.5 * tr["rr_y"] + 0.5 * smooth_a2 * tr["y2"]
-                noise = max(_EPS64 * g_y, 8.0 * _EPS32 * math.sqrt(tr["gnorm2"] * tr["dd"]))
-                in_noise_ball = tr["dd"] <= (8.0 * _EPS32 * t_k) ** 2 * tr["gnorm2"]
-                if tr["nnz"] == 0 or excess <= noise or in_noise_ball:
-                    break
-                t_k *= eta
-                bt_steps += 1
+            accepted = False
+            while not accepted:
+                # candidates t_k, t_k*eta, ... decided by ONE pass over A on the matrix cores (fos.h); ragged
+                # problems (two-pass fallback) evaluate one candidate per pass.
+                rows = st.trial_batch(t_k, eta, _BATCH) if use_batch else None
+                if rows is None:
+                    use_batch = False
+                    rows = [st.trial(t_k, with_residual=True)]
+                for tr in rows:
+                    if _armijo_accepts(tr, t_k, smooth_a2):
+                        accepted = True
+                        break
+                    t_k *= eta                                 # ref:195
+                    bt_steps += 1
             ls_call_times.append(time.perf_counter() - ls_t0)
             ls_call_iters.append(bt_steps)
             tau = t_k

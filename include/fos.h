@@ -95,6 +95,11 @@ int fos_gemv_pair(fos_problem* p, const float* y, float alpha2, float* grad, dou
  * Replaces g_smooth iterative_solvers.py:163-168 and compute_objective objective_functions.py:13-24. */
 int fos_residual_objective(fos_problem* p, const float* x, double* out3);
 
+/* Batched K5 on the matrix cores: out16[j] (device doubles) = ||A X_j - use_b*b||^2 for the nv <= 16 vectors stored as
+ * the columns of X (n x 16 floats, row-major: X[k*16 + j]); one pass over A.  FOS_ERR_UNSUPPORTED on fallback-path
+ * problems. */
+int fos_residual_batch(fos_problem* p, const float* X, int nv, int use_b, double* out16);
+
 /* Power iteration, iterative_solvers.py:45-60.  v_inout: start vector (n floats, need not be normalised),
  * overwritten with the last iterate.  Synchronises; *L_out and *iters_out are host values. */
 int fos_power_iter(fos_problem* p, float* v_inout, int n_iter, double tol, double* L_out, int* iters_out);
@@ -126,6 +131,11 @@ int fos_fista_update(fos_fista* f);
  * ||A y_k - b||^2, 0 }, grad including alpha2*y.  with_residual = 0 skips the pass over A (out8[5] = 0): the
  * cheap way to read ||grad|| for the gradient-norm stop (:179). */
 int fos_fista_trial(fos_fista* f, double t, int with_residual, double out8[8]);
+/* The same test for nv <= 16 candidate steps t, t*eta, t*eta^2, ... decided by ONE pass over A on the matrix
+ * cores (v_mfma_f32_16x16x4_f32, LDS-staged A tiles; the candidates are the N dimension).  out (host) = nv rows of
+ * 8 doubles, each laid out like out8 of fos_fista_trial.  Synchronises.  FOS_ERR_UNSUPPORTED when the problem runs
+ * the two-pass fallback (ragged shapes): callers then loop over fos_fista_trial.  SURVEY.md 8(f) rank 1. */
+int fos_fista_trial_batch(fos_fista* f, double t, double eta, int nv, double* out);
 int fos_fista_status_get(fos_fista* f, fos_fista_status* out);   /* synchronises */
 int fos_fista_get_x(fos_fista* f, double* dst);  /* enqueue copy of x_k (n doubles) to dst (device) */
 double* fos_fista_x(fos_fista* f);       /* device pointer to x_k (n doubles), borrowed     */
