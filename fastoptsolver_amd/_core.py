@@ -204,9 +204,13 @@ class Fista:
         with torch.cuda.device(self.prob.device):
             _lib.check(self.lib.fos_fista_run(self.h, int(iters)), "fos_fista_run")
 
-    def grad(self):
+    def grad(self, dual=False):
+        """Gradient pass at y_k; dual=True also leaves ||A x_k - b||^2 in status().rr_x (same pass over A)."""
         with torch.cuda.device(self.prob.device):
-            _lib.check(self.lib.fos_fista_grad(self.h), "fos_fista_grad")
+            if dual:
+                _lib.check(self.lib.fos_fista_grad_dual(self.h), "fos_fista_grad_dual")
+            else:
+                _lib.check(self.lib.fos_fista_grad(self.h), "fos_fista_grad")
 
     def update(self):
         with torch.cuda.device(self.prob.device):

@@ -22,7 +22,8 @@ class FistaParams(C.Structure):
 class FistaStatus(C.Structure):
     _fields_ = [("t_prev", C.c_double), ("beta", C.c_double), ("this_step", C.c_double), ("prev_step", C.c_double),
                 ("ratio", C.c_double), ("rr", C.c_double), ("gnorm2", C.c_double), ("xnorm1", C.c_double),
-                ("xnorm2", C.c_double), ("k", C.c_int64), ("stopped", C.c_int32), ("restarts", C.c_int32)]
+                ("xnorm2", C.c_double), ("rr_x", C.c_double), ("k", C.c_int64), ("stopped", C.c_int32),
+                ("restarts", C.c_int32)]
 
 
 _vp, _i64, _i32, _f32, _f64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_double
@@ -51,6 +52,7 @@ SIGNATURES = {
     "fos_fista_set_tau": (_i32, [_vp, _f64]),
     "fos_fista_run": (_i32, [_vp, _i32]),
     "fos_fista_grad": (_i32, [_vp]),
+    "fos_fista_grad_dual": (_i32, [_vp]),
     "fos_fista_update": (_i32, [_vp]),
     "fos_fista_trial": (_i32, [_vp, _f64, _i32, C.POINTER(_f64)]),   # out8
     "fos_fista_trial_batch": (_i32, [_vp, _f64, _f64, _i32, C.POINTER(_f64)]),

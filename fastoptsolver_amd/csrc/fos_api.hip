@@ -39,28 +39,33 @@ using fos::YSource;
 
 // ---- fused-kernel menu -------------------------------------------------------------------------------
 typedef void (*FusedLaunch)(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw,
-                            float* slabs, double* rr_part, int nwg, hipStream_t st);
+                            float* slabs, double* rr_part, double* rr2_part, int nwg, hipStream_t st);
 
-template <typename T, int THREADS, int K, int R, int MINW, bool WITH_G, int NBUF>
+template <typename T, int THREADS, int K, int R, int MINW, bool WITH_G, int NBUF, bool DUAL>
 void fused_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, float* slabs,
-                  double* rr_part, int nwg, hipStream_t st) {
-  hipLaunchKernelGGL((fos::gemv_pair_kernel<T, THREADS, K, R, true, MINW, WITH_G, NBUF, false>), dim3(nwg),
-                     dim3(THREADS), 0, st, reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part);
+                  double* rr_part, double* rr2_part, int nwg, hipStream_t st) {
+  hipLaunchKernelGGL((fos::gemv_pair_kernel<T, THREADS, K, R, true, MINW, WITH_G, NBUF, false, DUAL>), dim3(nwg),
+                     dim3(THREADS), 0, st, reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part,
+                     rr2_part);
 }
 
 struct MenuEntry {
   int dtype, threads, k, r;
-  FusedLaunch with_g, resid_only;
+  FusedLaunch with_g, resid_only, dual;   // dual may be null (geometry without a DUAL instantiation)
 };
 #define ENTRY(DT, T, TH, K, R, W) \
-  { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, 2>, fused_launch<T, TH, K, R, W, false, 2> }
-// NB register tiles in flight (profiles/r01_kbench_exp_*.log: 3 tiles are worth 1.5 % at n = 8192)
+  { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, 2, false>, fused_launch<T, TH, K, R, W, false, 2, false>, nullptr }
+// NB register tiles in flight (profiles/r01_kbench_exp_*.log: 3 tiles are worth 1.5 % at n = 8192); D: with DUAL
 #define ENTRY_NB(DT, T, TH, K, R, W, NB) \
-  { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, NB>, fused_launch<T, TH, K, R, W, false, NB> }
+  { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, NB, false>, fused_launch<T, TH, K, R, W, false, NB, false>, \
+    fused_launch<T, TH, K, R, W, true, 2, true> }
+#define ENTRY_D(DT, T, TH, K, R, W) \
+  { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, 2, false>, fused_launch<T, TH, K, R, W, false, 2, false>, \
+    fused_launch<T, TH, K, R, W, true, 2, true> }
 // Ordered by capacity (threads*k*EPC columns); first entry that fits n is the default.
 const MenuEntry kMenu[] = {
-    ENTRY(FOS_F32, float, 256, 1, 4, 2),   ENTRY(FOS_F32, float, 256, 2, 4, 2),  ENTRY(FOS_F32, float, 256, 4, 2, 2),
-    ENTRY_NB(FOS_F32, float, 512, 4, 2, 2, 3),   ENTRY(FOS_F32, float, 512, 8, 1, 2),  ENTRY(FOS_F32, float, 512, 8, 2, 2),
+    ENTRY_D(FOS_F32, float, 256, 1, 4, 2), ENTRY_D(FOS_F32, float, 256, 2, 4, 2), ENTRY_D(FOS_F32, float, 256, 4, 2, 2),
+    ENTRY_NB(FOS_F32, float, 512, 4, 2, 2, 3),   ENTRY_D(FOS_F32, float, 512, 8, 1, 2),  ENTRY(FOS_F32, float, 512, 8, 2, 2),
     ENTRY(FOS_F32, float, 1024, 4, 1, 4),  ENTRY(FOS_F32, float, 1024, 2, 2, 4),
     ENTRY(FOS_BF16, fos::bf16_t, 256, 1, 4, 2), ENTRY(FOS_BF16, fos::bf16_t, 256, 2, 2, 2),
     ENTRY(FOS_BF16, fos::bf16_t, 256, 4, 2, 2), ENTRY(FOS_BF16, fos::bf16_t, 1024, 2, 2, 4),
@@ -105,6 +110,7 @@ struct fos_problem {
   int slab_cap = 0, rr_cap = 0;
   float* slabs = nullptr;
   double* rr_part = nullptr;
+  double* rr2_part = nullptr;        // DUAL pass: partials of ||A x_k - b||^2
   float* rvec = nullptr;             // fallback: residual (m floats)
   float* gbuf = nullptr;             // n + 4 floats (internal, or caller-owned after fos_problem_set_gbuf)
   float* gbuf_own = nullptr;
@@ -169,7 +175,9 @@ int ensure_workspace(fos_problem* p) {
   const int need_rr = std::max(p->nwg, std::max(p->resid_grid, 1));
   if (need_rr > p->rr_cap) {
     if (p->rr_part) (void)hipFree(p->rr_part);
+    if (p->rr2_part) (void)hipFree(p->rr2_part);
     HIP_TRY(hipMalloc(&p->rr_part, (size_t)need_rr * sizeof(double)));
+    HIP_TRY(hipMalloc(&p->rr2_part, (size_t)need_rr * sizeof(double)));
     p->rr_cap = need_rr;
   }
   if (p->path == 1 && p->rvec == nullptr) HIP_TRY(hipMalloc(&p->rvec, (size_t)p->m * sizeof(float)));
@@ -208,18 +216,18 @@ int prof_mark(fos_problem* p, bool start) {
 }
 
 // Enqueue the A pass for `ys`.  with_g: also produce the slabs (A^T r).  Returns number of rr partials.
-int launch_pass_inner(fos_problem* p, const YSource& ys, const float* b, bool with_g, int* n_rr);
-int launch_pass(fos_problem* p, const YSource& ys, const float* b, bool with_g, int* n_rr) {
+int launch_pass_inner(fos_problem* p, const YSource& ys, const float* b, bool with_g, int* n_rr, bool dual);
+int launch_pass(fos_problem* p, const YSource& ys, const float* b, bool with_g, int* n_rr, bool dual = false) {
   int rc = prof_mark(p, true);
   if (rc) return rc;
-  if ((rc = launch_pass_inner(p, ys, b, with_g, n_rr))) return rc;
+  if ((rc = launch_pass_inner(p, ys, b, with_g, n_rr, dual))) return rc;
   return prof_mark(p, false);
 }
 
-int launch_pass_inner(fos_problem* p, const YSource& ys, const float* b, bool with_g, int* n_rr) {
+int launch_pass_inner(fos_problem* p, const YSource& ys, const float* b, bool with_g, int* n_rr, bool dual) {
   if (p->path == 0) {
-    FusedLaunch fn = with_g ? p->entry->with_g : p->entry->resid_only;
-    fn(p->A, p->lda, b, p->m, (int)p->n, ys, p->rows_per_wg, p->slabs, p->rr_part, p->nwg, p->stream);
+    FusedLaunch fn = dual ? p->entry->dual : (with_g ? p->entry->with_g : p->entry->resid_only);
+    fn(p->A, p->lda, b, p->m, (int)p->n, ys, p->rows_per_wg, p->slabs, p->rr_part, p->rr2_part, p->nwg, p->stream);
     LAUNCH_CHECK();
     *n_rr = p->nwg;
     return FOS_OK;
@@ -367,7 +375,7 @@ int fos_problem_profile_read(fos_problem* p, double* ms_total, int64_t* launches
 int fos_problem_destroy(fos_problem* p) {
   if (!p) return FOS_OK;
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
-  void* bufs[] = {p->slabs, p->rr_part, p->rvec, p->gbuf_own, p->ybuf, p->dscal, p->part, p->xp, p->q_part, p->bt_out};
+  void* bufs[] = {p->slabs, p->rr_part, p->rr2_part, p->rvec, p->gbuf_own, p->ybuf, p->dscal, p->part, p->xp, p->q_part, p->bt_out};
   for (void* q : bufs)
     if (q) (void)hipFree(q);
   delete p;
@@ -602,6 +610,30 @@ int fos_fista_grad(fos_fista* f) {
   return launch_slab_reduce(p, n_rr, p->gbuf, &f->scal->rr, &f->scal->stopped);
 }
 
+int fos_fista_grad_dual(fos_fista* f) {
+  if (!f) return fail(FOS_ERR_ARG, "fos_fista_grad_dual: null");
+  fos_problem* p = f->p;
+  int n_rr = 0, rc;
+  if (p->path == 0 && p->entry->dual != nullptr) {
+    if ((rc = launch_pass(p, fista_source(f), p->b, true, &n_rr, true))) return rc;
+    if ((rc = launch_slab_reduce(p, n_rr, p->gbuf, &f->scal->rr, &f->scal->stopped))) return rc;
+    hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->rr2_part, n_rr, 1,
+                       &f->scal->rr_x);
+    LAUNCH_CHECK();
+    return FOS_OK;
+  }
+  // no DUAL instantiation (fallback path / wide geometries): a separate residual pass on x_k, then the gradient
+  hipLaunchKernelGGL(fos::cast_f64_f32_kernel, dim3(grid_1d(p->n, 256, 1024)), dim3(256), 0, p->stream, f->x_cur, p->ybuf,
+                     p->n);
+  LAUNCH_CHECK();
+  YSource ys{p->ybuf, nullptr, nullptr, nullptr, &f->scal->stopped};
+  if ((rc = launch_pass(p, ys, p->b, false, &n_rr))) return rc;
+  hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->rr_part, n_rr, 1,
+                     &f->scal->rr_x);
+  LAUNCH_CHECK();
+  return fos_fista_grad(f);
+}
+
 int fos_fista_update(fos_fista* f) {
   if (!f) return fail(FOS_ERR_ARG, "fos_fista_update: null");
   fos_problem* p = f->p;
@@ -676,6 +708,7 @@ int fos_fista_status_get(fos_fista* f, fos_fista_status* out) {
   HIP_TRY(hipStreamSynchronize(f->p->stream));
   out->t_prev = h.t_prev; out->beta = h.beta; out->this_step = h.this_step; out->prev_step = h.prev_step;
   out->ratio = h.ratio; out->rr = h.rr; out->gnorm2 = h.gnorm2; out->xnorm1 = h.xnorm1; out->xnorm2 = h.xnorm2;
+  out->rr_x = h.rr_x;
   out->k = h.k; out->stopped = h.stopped; out->restarts = h.restarts;
   return FOS_OK;
 }

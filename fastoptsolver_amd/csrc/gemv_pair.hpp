@@ -84,14 +84,19 @@ __device__ inline double wave_sum(double v) {
 // NBUF register tiles (NBUF-1 steps in flight behind the one being consumed).  IL = true deals rows to the
 // workgroups round-robin in R-row groups (all CUs stream one contiguous window) instead of one contiguous
 // block per workgroup; rows_per_wg is then ignored.
-template <typename T, int THREADS, int K, int R, bool NT, int MINW, bool WITH_G = true, int NBUF = 2, bool IL = false>
+// DUAL = true (FISTA source only) also dots every row with x_k itself and returns rr2_part[w] = sum (A_i.x_k - b_i)^2:
+// the history objective f(x_k) (iterative_solvers.py:225-230, :321) comes out of the SAME pass over A that produces
+// the gradient at y_k, instead of the extra pass the reference pays per iteration.
+template <typename T, int THREADS, int K, int R, bool NT, int MINW, bool WITH_G = true, int NBUF = 2, bool IL = false,
+          bool DUAL = false>
 __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
     const T* __restrict__ A, int64_t lda, const float* __restrict__ b, int64_t m, int n, YSource ys,
-    int64_t rows_per_wg, float* __restrict__ slabs, double* __restrict__ rr_part) {
+    int64_t rows_per_wg, float* __restrict__ slabs, double* __restrict__ rr_part, double* __restrict__ rr2_part) {
   using Tr = ElemTraits<T>;
   constexpr int EPC = Tr::EPC;
   constexpr int NW = THREADS / 64;
-  __shared__ float red[2][R][NW];
+  constexpr int NV = DUAL ? 2 : 1;
+  __shared__ float red[2][R * NV][NW];
 
   if (ys.stopped != nullptr && *ys.stopped != 0) return;
 
@@ -105,6 +110,7 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
   // ---- prologue: this thread's slice of y, straight into registers --------------------------------
   float yv[K][EPC];
   float gv[K][EPC];
+  float xv[DUAL ? K : 1][EPC];
   bool live[K];
   const double beta = (ys.y == nullptr) ? *ys.beta : 0.0;
 #pragma unroll
@@ -113,6 +119,10 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
     live[c] = col < n;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { yv[c][e] = 0.f; gv[c][e] = 0.f; }
+    if constexpr (DUAL) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) xv[c][e] = live[c] ? (float)ys.x_cur[col + e] : 0.f;
+    }
     if (live[c]) {
 #pragma unroll
       for (int q = 0; q < EPC / 4; ++q) {
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
   const int64_t nsteps = nrows > first ? (nrows - first + group - 1) / group : 0;
   const char* base = reinterpret_cast<const char*>(A) + (int64_t)tid * 16;
   const int64_t row_bytes = lda * (int64_t)sizeof(T);
-  double rr = 0.0;
+  double rr = 0.0, rr2 = 0.0;
 
   u32x4 tile[NBUF][R][K];
   auto issue = [&](int buf, int64_t step) {
@@ -152,10 +162,10 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
     }
   };
   auto consume = [&](int buf, int64_t step) {
-    float part[R];
+    float part[R * NV];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      float acc0 = 0.f, acc1 = 0.f;
+      float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
 #pragma unroll
       for (int c = 0; c < K; ++c) {
         float a[EPC];
@@ -164,14 +174,19 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
         for (int e = 0; e < EPC; e += 2) {
           acc0 = fmaf(a[e], yv[c][e], acc0);
           acc1 = fmaf(a[e + 1], yv[c][e + 1], acc1);
+          if constexpr (DUAL) {
+            acc2 = fmaf(a[e], xv[c][e], acc2);
+            acc3 = fmaf(a[e + 1], xv[c][e + 1], acc3);
+          }
         }
       }
       part[r] = wave_sum(acc0 + acc1);
+      if constexpr (DUAL) part[R + r] = wave_sum(acc2 + acc3);
     }
     const int pb = (int)(step & 1);
     if (lane == 0) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) red[pb][r][wave] = part[r];
+      for (int r = 0; r < R * NV; ++r) red[pb][r][wave] = part[r];
     }
     __syncthreads();
     float res[R];
@@ -181,13 +196,20 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
 #pragma unroll
       for (int w = 0; w < NW; ++w) s += red[pb][r][w];
       const int64_t row = row_lo + first + step * group + r;
+      const float bi = (b != nullptr && row < row_hi) ? b[row] : 0.f;
       if (row < row_hi) {
-        if (b != nullptr) s -= b[row];
+        s -= bi;
         rr += (double)s * (double)s;
       } else {
         s = 0.f;
       }
       res[r] = s;
+      if constexpr (DUAL) {
+        float s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s2 += red[pb][R + r][w];
+        if (row < row_hi) { s2 -= bi; rr2 += (double)s2 * (double)s2; }
+      }
     }
     if constexpr (WITH_G) {
 #pragma unroll
@@ -229,7 +251,10 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
       }
     }
   }
-  if (tid == 0) rr_part[blockIdx.x] = rr;
+  if (tid == 0) {
+    rr_part[blockIdx.x] = rr;
+    if constexpr (DUAL) rr2_part[blockIdx.x] = rr2;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------

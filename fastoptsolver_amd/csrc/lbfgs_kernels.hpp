@@ -215,6 +215,10 @@ __global__ __launch_bounds__(256) void vec_axpby_kernel(float a, const float* __
   }
 }
 
+__global__ __launch_bounds__(256) void cast_f64_f32_kernel(const double* __restrict__ in, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = (float)in[i];
+}
+
 // grad_out = gbuf + alpha2 * y   (L-BFGS fg: lbfgs.py:50-51)
 __global__ __launch_bounds__(256) void add_l2_kernel(const float* __restrict__ gbuf, float alpha2,
                                                      const float* __restrict__ y, float* __restrict__ out, int64_t n) {

@@ -32,6 +32,7 @@ struct FistaScalars {
   double gnorm2;       // ||grad||^2 of the last gradient (smooth part, incl. alpha2*y)
   double xnorm1;       // ||x_k||_1   (filled by the update kernel: free by-products for the objective)
   double xnorm2;       // ||x_k||_2^2
+  double rr_x;         // ||A x_k - b||^2 of the iterate the last DUAL gradient pass started from
   long long k;         // completed iterations
   int stopped;         // STOP_*
   int restarts;

@@ -149,12 +149,19 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
             del grad_call_times[k:]
         return st
 
+    # History objective f(x_k) without the reference's extra pass per iteration (ref:225-230, :321): the DUAL
+    # gradient pass of iteration k also returns ||A x_k - b||^2, so f(x_k) is appended one iteration late and only
+    # the very last iterate needs a residual pass of its own.
+    owed = None                  # (||x||_1, ||x||_2^2) of the newest iterate whose objective is not recorded yet
     for _ in range(max_iter):
         ev = gtimer.start()
-        st.grad()                                            # ref:173-175 (alpha2*y is added by the consumers)
+        st.grad(dual=owed is not None)                        # ref:173-175 (alpha2*y is added by the consumers)
         gtimer.stop(ev)
         if grad_tol_check and tol > 0.0:                      # ref:179
             if math.sqrt(st.trial(tau, with_residual=False)["gnorm2"]) < tol:
+                if owed is not None:
+                    history["obj"].append(history_obj(st.status().rr_x, owed[1], owed[0]))
+                    owed = None
                 break
         if backtracking:                                      # ref:183-197 / ref:298-312 / ref:92-108
             bt_steps = 0
@@ -181,10 +188,12 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
         st.update()                                           # ref:200-221
         if history is not None or log is not None:
             xk = st.x_tensor()
-            if history is not None:
-                history["x"].append(_core.from_device_vec(xk, like))
-                history["obj"].append(history_obj(prob, xk))
             s = st.status()
+            if history is not None:
+                if owed is not None:
+                    history["obj"].append(history_obj(s.rr_x, owed[1], owed[0]))
+                history["x"].append(_core.from_device_vec(xk, like))
+                owed = (s.xnorm1, s.xnorm2)
             if log is not None:
                 log["x"].append(_core.from_device_vec(xk, like))
                 log["t"].append(tau)
@@ -193,14 +202,16 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
             s = st.status() if (tol > 0.0 or tol_ratio > 0.0) else None
         if s is not None and s.stopped != _lib.STOP_NONE:     # ref:238, :242
             break
+    if owed is not None:
+        rr, x2, x1 = prob.residual_objective(st.x_tensor())
+        history["obj"].append(history_obj(rr, x2, x1))
     gtimer.flush()
     return st
 
 
 def _objective_by_alpha(alpha1, alpha2):
     """History objective of fista(): driven by alpha>0, not by reg_type.  ref:225-230"""
-    def obj(prob, xk):
-        rr, x2, x1 = prob.residual_objective(xk)
+    def obj(rr, x2, x1):
         val = 0.5 * rr
         if alpha2 > 0:
             val += 0.5 * alpha2 * x2
@@ -215,8 +226,7 @@ def _objective_by_reg(reg_type, alpha1, alpha2):
     if reg_type not in ("lasso", "ridge", "elasticnet"):
         raise ValueError(f"Unsupported reg_type='{reg_type}'")
 
-    def obj(prob, xk):
-        rr, x2, x1 = prob.residual_objective(xk)
+    def obj(rr, x2, x1):
         val = 0.5 * rr
         if reg_type in ("ridge", "elasticnet"):
             val += 0.5 * alpha2 * x2

@@ -57,6 +57,7 @@ typedef struct fos_fista_status {
   double gnorm2;    /* ||grad_smooth(y)||^2 of the last update */
   double xnorm1;    /* ||x_k||_1   */
   double xnorm2;    /* ||x_k||_2^2 */
+  double rr_x;      /* ||A x_k - b||^2 at the iterate the last fos_fista_grad_dual started from */
   int64_t k;        /* completed iterations */
   int32_t stopped;  /* FOS_STOP_* */
   int32_t restarts;
@@ -123,6 +124,9 @@ int fos_fista_run(fos_fista* f, int iters);
  *   fos_fista_grad    gbuf[0..n) = A^T (A y_k - b) (WITHOUT alpha2*y), gbuf[n] = ||A y_k - b||^2 (float)
  *   fos_fista_update  prox + momentum from gbuf (after an optional all-reduce of gbuf[0..n]) */
 int fos_fista_grad(fos_fista* f);
+/* fos_fista_grad that ALSO returns ||A x_k - b||^2 (status.rr_x) from the same pass over A: the history objective
+ * f(x_k) (:225-230, :321) without the extra pass per iteration the reference pays. */
+int fos_fista_grad_dual(fos_fista* f);
 int fos_fista_update(fos_fista* f);
 /* Armijo trial at step t (:187-191) in cancellation-free form.  With x_tmp = prox(y_k - t*grad) and
  * dlt = x_tmp - y_k the reference's test g(x_tmp) <= g(y_k) + C*grad.dlt is, exactly (g is quadratic),

@@ -59,7 +59,7 @@ template <typename T, int THREADS, int K, int R, bool NT, int MINW, int NBUF = 2
 void launch_variant(const void* A, int64_t lda, const float* b, int64_t m, int n, fos::YSource ys, int64_t rpw,
                     float* slabs, double* rr, int nwg, hipStream_t st) {
   hipLaunchKernelGGL((fos::gemv_pair_kernel<T, THREADS, K, R, NT, MINW, true, NBUF, IL>), dim3(nwg), dim3(THREADS), 0, st,
-                     (const T*)A, lda, b, m, n, ys, rpw, slabs, rr);
+                     (const T*)A, lda, b, m, n, ys, rpw, slabs, rr, (double*)nullptr);
 }
 
 __global__ void to_bf16(const float* in, unsigned short* out, size_t n) {
