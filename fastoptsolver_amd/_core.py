@@ -36,12 +36,25 @@ def to_device_vec(x, device=None):
     return t.to(device=dev, dtype=torch.float32).contiguous()
 
 
+class Like:
+    """What the caller handed in (so results come back as the same kind) without keeping the object alive."""
+
+    def __init__(self, obj):
+        self.tensor = is_tensor(obj)
+        if self.tensor:
+            self.dtype = obj.dtype if obj.dtype in (torch.float32, torch.float64) else torch.float32
+            self.device = obj.device
+
+
 def from_device_vec(t, like):
-    """Return `t` as the same kind of object the caller handed in: ndarray float64, or a tensor on t's device
-    in the caller's floating dtype (bf16 inputs get float32 back)."""
+    """Return `t` as the same kind of object the caller handed in: ndarray float64, or a tensor on the caller's
+    device in the caller's floating dtype (bf16 inputs get float32 back)."""
+    if isinstance(like, Like):
+        if like.tensor:
+            return t.to(device=like.device, dtype=like.dtype, copy=True)
+        return t.detach().to("cpu", torch.float64).numpy()
     if is_tensor(like):
-        dt = like.dtype if like.dtype in (torch.float32, torch.float64) else torch.float32
-        return t.to(dt).clone() if t.dtype == dt else t.to(dt)
+        return from_device_vec(t, Like(like))
     return t.detach().to("cpu", torch.float64).numpy()
 
 
@@ -55,7 +68,7 @@ class Problem:
     def __init__(self, A, b=None, dtype=None):
         require_gpu()
         lib = _lib.load()
-        self.like = A
+        self.like = Like(A)
         want_bf16 = (dtype in ("bf16", torch.bfloat16)) or (dtype is None and is_tensor(A) and A.dtype == torch.bfloat16)
         tdtype = torch.bfloat16 if want_bf16 else torch.float32
         dev = A.device if is_tensor(A) and A.is_cuda else torch.device("cuda", torch.cuda.current_device())

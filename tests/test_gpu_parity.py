@@ -490,3 +490,32 @@ def test_batched_and_sequential_line_search_agree(fos):
     assert out[True][1] == out[False][1]
     assert _data.rel(out[True][0], out[False][0]) < 1e-9
     assert sum(out[True][1]) > 0
+
+
+def test_lbfgs_boston_end_point(fos):
+    """Config-1 data through L-BFGS.  cond(A^T A) ~ 1e9: with float32 vectors the PATH differs from SciPy's float64
+    run after the second iterate (curvature pairs are differences of noisy gradients), the END POINT does not."""
+    fx = _data.load("boston")
+    A, b = fx["boston/A"], fx["boston/b"]
+    s = fos.LBFGSSolver("ridge", 0.0, 0.5).fit(A, b)
+    # SURVEY 8(c) known answer of the reference for this call
+    assert np.allclose(s.x_, [5.04537675, 0.14409563, -0.01939221, -0.05905357, 1.53772434], rtol=2e-4, atol=2e-5)
+    assert s.final_obj_ == pytest.approx(2077.060367882381, rel=1e-6)
+    assert _data.rel(s.x_, fx["boston/lbfgs/enet_tiny1/x"]) < 5e-5
+    assert s.task_.startswith("CONVERGENCE")
+    assert _data.rel(s.iterates_[0], fx["boston/lbfgs/enet_tiny1/iterates"][0]) < 1e-6     # first step identical
+
+
+def test_ista_from_nonzero_start(fos):
+    A, b, fx = _data.problem("ragged")
+    x0 = np.random.default_rng(0).standard_normal(A.shape[1])
+    a1 = 0.05 * float(np.max(np.abs(A.T @ b)))
+    L = float(fx["ragged/ista/L"]) + 0.3
+    ls = fos.LeastSquares(A, b, 0.3)
+    x = fos.ista(x0, ls, ls.grad, fos.L1Prox(a1), L, max_iter=30)
+    x_ref = orc.ista(x0, lambda z: orc.smooth_value(A, b, z, 0.3), lambda z: orc.gram_gradient(A, z, b, 0.3)[0],
+                     lambda v, t: orc.prox_l1(v, t * a1), L, max_iter=30)
+    assert _data.rel(x, x_ref) < TOL
+    # CPU tensors in -> CPU tensors out
+    xt = fos.ista(torch.from_numpy(x0), ls, ls.grad, fos.L1Prox(a1), L, max_iter=30)
+    assert isinstance(xt, torch.Tensor) and not xt.is_cuda and _data.rel(xt.numpy(), x_ref) < TOL
