@@ -134,6 +134,11 @@ struct fos_problem {
 struct fos_fista {
   fos_problem* p = nullptr;
   fos::FistaParams prm{};
+  // host mirror of the momentum scalars, valid while only plain fos_fista_run calls advance the state
+  bool host_valid = false;
+  double h_t = 1.0, h_beta = 0.0;
+  long long h_k = 0;
+  double* part2 = nullptr;           // ping-pong partials for plain runs: 2 * nupd * 4 doubles
   double *x_cur = nullptr, *x_prev = nullptr;   // fp64 iterate state
   float* dlt = nullptr;                         // trial difference vector x_tmp - y_k (fp32)
   fos::FistaScalars* scal = nullptr;
@@ -512,18 +517,19 @@ int fos_fista_create(fos_problem* p, fos_fista** out) {
   if (he == hipSuccess) he = hipMalloc(&f->dlt, (size_t)p->n * sizeof(float));
   if (he == hipSuccess) he = hipMalloc(&f->scal, sizeof(fos::FistaScalars));
   if (he == hipSuccess) he = hipMalloc(&f->out5, 8 * sizeof(double));
+  f->nupd = (int)((p->n + fos::RCOLS - 1) / fos::RCOLS);
+  if (he == hipSuccess) he = hipMalloc(&f->part2, (size_t)2 * f->nupd * 4 * sizeof(double));
   if (he != hipSuccess) {
     fos_fista_destroy(f);
     return fail(FOS_ERR_HIP, std::string("fos_fista_create: ") + hipGetErrorString(he));
   }
-  f->nupd = (int)((p->n + fos::RCOLS - 1) / fos::RCOLS);
   *out = f;
   return FOS_OK;
 }
 
 int fos_fista_destroy(fos_fista* f) {
   if (!f) return FOS_OK;
-  void* bufs[] = {f->x_cur, f->x_prev, f->dlt, f->scal, f->out5};
+  void* bufs[] = {f->x_cur, f->x_prev, f->dlt, f->scal, f->out5, f->part2};
   for (void* q : bufs)
     if (q) (void)hipFree(q);
   delete f;
@@ -563,6 +569,10 @@ int fos_fista_reset(fos_fista* f, const fos_fista_params* prm, const double* x0)
   init.ratio = INFINITY;
   HIP_TRY(hipMemcpyAsync(f->scal, &init, sizeof(init), hipMemcpyHostToDevice, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));   // `init` is a stack object
+  f->host_valid = true;
+  f->h_t = 1.0;
+  f->h_beta = 0.0;
+  f->h_k = 0;
   return FOS_OK;
 }
 
@@ -573,7 +583,7 @@ int fos_fista_set_tau(fos_fista* f, double tau) {
 }
 
 static YSource fista_source(fos_fista* f) {
-  return YSource{nullptr, f->x_cur, f->x_prev, &f->scal->beta, &f->scal->stopped};
+  return YSource{nullptr, f->x_cur, f->x_prev, &f->scal->beta, &f->scal->stopped, 0.0};
 }
 
 static int launch_finalize(fos_fista* f, int n_rr) {
@@ -584,18 +594,74 @@ static int launch_finalize(fos_fista* f, int n_rr) {
   return FOS_OK;
 }
 
+// Momentum of the iteration that follows iteration index k (0-based), given t_k: iterative_solvers.py:215-216, :330.
+static void host_momentum(const fos::FistaParams& prm, long long k, double* t, double* beta) {
+  if (prm.mode == fos::MODE_FISTA) {
+    const double t_new = 0.5 * (1.0 + std::sqrt(1.0 + 4.0 * (*t) * (*t)));
+    *beta = (*t - 1.0) / t_new;
+    *t = t_new;
+  } else if (prm.mode == fos::MODE_DELTA) {
+    const double kk = (double)(k + 1);
+    *beta = kk / (kk + 1.0 + prm.delta);
+  } else {
+    *beta = 0.0;
+  }
+}
+
+static void launch_update_from_slabs(fos_fista* f, double* part, int host_beta, double beta_val) {
+  fos_problem* p = f->p;
+  if (p->vec4)
+    hipLaunchKernelGGL((fos::fista_update_kernel<true, true>), dim3(f->nupd), dim3(256), 0, p->stream, p->slabs,
+                       p->nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
+                       beta_val);
+  else
+    hipLaunchKernelGGL((fos::fista_update_kernel<true, false>), dim3(f->nupd), dim3(256), 0, p->stream, p->slabs,
+                       p->nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
+                       beta_val);
+}
+
 int fos_fista_run(fos_fista* f, int iters) {
   if (!f || iters < 0) return fail(FOS_ERR_ARG, "fos_fista_run: bad argument");
   fos_problem* p = f->p;
+  if (iters == 0) return FOS_OK;
+  // Plain run: no data-dependent control (adaptive restart / stopping tolerances).  t_k and beta_k are then a fixed
+  // sequence: the host passes beta_k to both kernels by value, and the scalar bookkeeping kernel runs once per call
+  // instead of once per iteration (two launches per iteration instead of three).
+  const bool plain = !(f->prm.mode == fos::MODE_FISTA && f->prm.adaptive_restart) && f->prm.tol_step == 0.0 &&
+                     f->prm.tol_ratio == 0.0;
+  if (plain) {
+    if (!f->host_valid) {
+      fos_fista_status st;
+      int rc = fos_fista_status_get(f, &st);      // synchronises once after split-mode / device-driven calls
+      if (rc) return rc;
+      if (st.stopped != FOS_STOP_NONE) return FOS_OK;
+      f->h_t = st.t_prev; f->h_beta = st.beta; f->h_k = st.k;
+      f->host_valid = true;
+    }
+    const size_t psz = (size_t)f->nupd * 4;
+    int n_rr = 0;
+    for (int it = 0; it < iters; ++it) {
+      YSource ys{nullptr, f->x_cur, f->x_prev, nullptr, &f->scal->stopped, f->h_beta};
+      int rc;
+      if ((rc = launch_pass(p, ys, p->b, true, &n_rr))) return rc;
+      launch_update_from_slabs(f, f->part2 + (size_t)(f->h_k & 1) * psz, 1, f->h_beta);
+      LAUNCH_CHECK();
+      host_momentum(f->prm, f->h_k, &f->h_t, &f->h_beta);
+      f->h_k += 1;
+    }
+    const long long last = f->h_k - 1;
+    const double* cur = f->part2 + (size_t)(last & 1) * psz;
+    const double* prev = iters >= 2 ? f->part2 + (size_t)((last - 1) & 1) * psz : nullptr;
+    hipLaunchKernelGGL(fos::fista_finalize_plain_kernel, dim3(1), dim3(64), 0, p->stream, cur, prev, f->nupd, p->rr_part,
+                       n_rr, f->scal, f->h_t, f->h_beta, f->h_k);
+    LAUNCH_CHECK();
+    return FOS_OK;
+  }
+  f->host_valid = false;
   for (int it = 0; it < iters; ++it) {
     int n_rr = 0, rc;
     if ((rc = launch_pass(p, fista_source(f), p->b, true, &n_rr))) return rc;
-    if (p->vec4)
-      hipLaunchKernelGGL((fos::fista_update_kernel<true, true>), dim3(f->nupd), dim3(256), 0, p->stream, p->slabs,
-                         p->nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, p->part);
-    else
-      hipLaunchKernelGGL((fos::fista_update_kernel<true, false>), dim3(f->nupd), dim3(256), 0, p->stream, p->slabs,
-                         p->nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, p->part);
+    launch_update_from_slabs(f, p->part, 0, 0.0);
     LAUNCH_CHECK();
     if ((rc = launch_finalize(f, n_rr))) return rc;
   }
@@ -639,11 +705,12 @@ int fos_fista_update(fos_fista* f) {
   fos_problem* p = f->p;
   if (p->vec4)
     hipLaunchKernelGGL((fos::fista_update_kernel<false, true>), dim3(f->nupd), dim3(256), 0, p->stream,
-                       (const float*)nullptr, 0, p->gbuf, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, p->part);
+                       (const float*)nullptr, 0, p->gbuf, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, p->part, 0, 0.0);
   else
     hipLaunchKernelGGL((fos::fista_update_kernel<false, false>), dim3(f->nupd), dim3(256), 0, p->stream,
-                       (const float*)nullptr, 0, p->gbuf, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, p->part);
+                       (const float*)nullptr, 0, p->gbuf, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, p->part, 0, 0.0);
   LAUNCH_CHECK();
+  f->host_valid = false;
   return launch_finalize(f, 0);
 }
 

@@ -33,9 +33,14 @@ struct YSource {
   const float* y;        // explicit y (power iteration, L-BFGS, trial points) or nullptr
   const double* x_cur;   // x_k
   const double* x_prev;  // x_{k-1}
-  const double* beta;    // device scalar
+  const double* beta;    // device scalar, or nullptr: use beta_val (host-driven momentum, see fos_fista_run)
   const int* stopped;    // device flag: non-zero -> kernel is a no-op (solver already stopped)
+  double beta_val;
 };
+
+__device__ inline double source_beta(const YSource& ys) {
+  return ys.y != nullptr ? 0.0 : (ys.beta != nullptr ? *ys.beta : ys.beta_val);
+}
 
 __device__ inline double form_y(double xc, double xp, double beta) { return xc + beta * (xc - xp); }
 
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
   float gv[K][EPC];
   float xv[DUAL ? K : 1][EPC];
   bool live[K];
-  const double beta = (ys.y == nullptr) ? *ys.beta : 0.0;
+  const double beta = source_beta(ys);
 #pragma unroll
   for (int c = 0; c < K; ++c) {
     const int col = (c * THREADS + tid) * EPC;
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(256) void residual_rows_kernel(const T* __restrict_
   if (ys.stopped != nullptr && *ys.stopped != 0) return;
   __shared__ double wsum[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const double beta = (ys.y == nullptr) ? *ys.beta : 0.0;
+  const double beta = source_beta(ys);
   double rr = 0.0;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < m; row += (int64_t)gridDim.x * 4) {
     const T* ar = A + row * lda;

@@ -167,12 +167,12 @@ __global__ __launch_bounds__(256) void fista_update_kernel(const float* __restri
                                                           const float* __restrict__ gbuf, int n,
                                                           double* __restrict__ x_cur, double* __restrict__ x_prev,
                                                           const FistaScalars* __restrict__ scal, FistaParams prm,
-                                                          double* __restrict__ part) {
+                                                          double* __restrict__ part, int host_beta, double beta_val) {
   if (scal->stopped != 0) return;
   __shared__ f32x4 lds[RG][RQ];
   __shared__ double dl[4 * 4];
   const int col0 = blockIdx.x * RCOLS;
-  const double beta = scal->beta;
+  const double beta = host_beta ? beta_val : scal->beta;
   float g[4] = {0.f, 0.f, 0.f, 0.f};
   int col, cnt = 0;
   bool owner;
@@ -289,6 +289,41 @@ __global__ __launch_bounds__(64) void fista_finalize_kernel(const double* __rest
   if (prm.tol_step > 0.0 && step < prm.tol_step) stop = STOP_STEP;
   if (stop == STOP_NONE && prm.tol_ratio > 0.0 && ratio < prm.tol_ratio) stop = STOP_RATIO;
   scal->stopped = stop;
+}
+
+// Plain runs (no adaptive restart, no stopping tolerance): t_k and beta_k do not depend on the data, the host hands
+// beta_k to the kernels by value and this kernel runs ONCE per fos_fista_run call to bring the device scalars up to
+// date: step norms from the partials of the last two iterations, momentum scalars from the host.
+__global__ __launch_bounds__(64) void fista_finalize_plain_kernel(const double* __restrict__ part_cur,
+                                                                 const double* __restrict__ part_prev, int nparts,
+                                                                 const double* __restrict__ rr_part, int n_rr,
+                                                                 FistaScalars* __restrict__ scal, double t_prev,
+                                                                 double beta_next, long long k_total) {
+  if (scal->stopped != 0) return;
+  double s[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < nparts; i += 64) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] += part_cur[i * 4 + j];
+    if (part_prev != nullptr) s[4] += part_prev[i * 4];
+  }
+  double rr = 0.0;
+  for (int i = threadIdx.x; i < n_rr; i += 64) rr += rr_part[i];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) s[i] = wave_sum(s[i]);
+  rr = wave_sum(rr);
+  if (threadIdx.x != 0) return;
+  const double step = sqrt(s[0]);
+  const double prev = part_prev != nullptr ? sqrt(s[4]) : scal->this_step;
+  scal->prev_step = prev;
+  scal->this_step = step;
+  scal->ratio = prev > 0.0 ? step / prev : INFINITY;
+  scal->gnorm2 = s[1];
+  scal->xnorm1 = s[2];
+  scal->xnorm2 = s[3];
+  scal->rr = rr;
+  scal->t_prev = t_prev;
+  scal->beta = beta_next;
+  scal->k = k_total;
 }
 
 // ---------------------------------------------------------------------------------------------------------
