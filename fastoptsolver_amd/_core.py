@@ -118,8 +118,9 @@ class Problem:
     def tune(self, threads, chunks, rows, workgroups=0):
         _lib.check(self.lib.fos_problem_tune(self.h, threads, chunks, rows, workgroups), "fos_problem_tune")
 
-    def profile(self, enable=True):
-        _lib.check(self.lib.fos_problem_profile(self.h, int(bool(enable))), "fos_problem_profile")
+    def profile(self, every=1):
+        """Bracket every `every`-th A-pass launch with HIP events (0 / False = off)."""
+        _lib.check(self.lib.fos_problem_profile(self.h, int(every)), "fos_problem_profile")
 
     def profile_read(self):
         """(device milliseconds, launches) of the A-pass kernel since the last read; synchronises."""

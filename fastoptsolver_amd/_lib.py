@@ -41,6 +41,7 @@ SIGNATURES = {
     "fos_problem_profile": (_i32, [_vp, _i32]),
     "fos_problem_profile_read": (_i32, [_vp, C.POINTER(_f64), C.POINTER(_i64)]),
     "fos_gemv_pair": (_i32, [_vp, _vp, _f32, _vp, _vp]),
+    "fos_gemv_pair_f64": (_i32, [_vp, _vp, _f64, _vp, _vp]),
     "fos_residual_objective": (_i32, [_vp, _vp, _vp]),
     "fos_residual_batch": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "fos_power_iter": (_i32, [_vp, _vp, _i32, _f64, C.POINTER(_f64), C.POINTER(_i32)]),
@@ -63,6 +64,8 @@ SIGNATURES = {
     "fos_lbfgs_two_loop": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
     "fos_vec_stats": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "fos_vec_axpby": (_i32, [_f64, _vp, _f64, _vp, _vp, _i64, _vp]),
+    "fos_vec_stats_f64": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "fos_vec_axpby_f64": (_i32, [_f64, _vp, _f64, _vp, _vp, _i64, _vp]),
 }
 
 _lib = None

@@ -111,7 +111,7 @@ struct fos_problem {
   float* slabs = nullptr;
   double* rr_part = nullptr;
   double* rr2_part = nullptr;        // DUAL pass: partials of ||A x_k - b||^2
-  float* rvec = nullptr;             // fallback: residual (m floats)
+  double* rvec = nullptr;            // fallback: residual (m doubles)
   float* gbuf = nullptr;             // n + 4 floats (internal, or caller-owned after fos_problem_set_gbuf)
   float* gbuf_own = nullptr;
   float* ybuf = nullptr;             // n floats: aligned copy of a caller vector when needed
@@ -124,7 +124,9 @@ struct fos_problem {
   double* bt_out = nullptr;          // 128 doubles
   int64_t n_pad = 0;
   // optional kernel timing (fos_problem_profile)
-  bool profiling = false;
+  int profiling = 0;                 // 0 off, N: bracket every N-th launch of the A pass
+  int64_t prof_seq = 0;
+  bool prof_open = false;
   std::vector<hipEvent_t> ev_pool;   // pairs: [2i] start, [2i+1] stop
   size_t ev_used = 0;
   double prof_ms = 0.0;
@@ -185,7 +187,7 @@ int ensure_workspace(fos_problem* p) {
     HIP_TRY(hipMalloc(&p->rr2_part, (size_t)need_rr * sizeof(double)));
     p->rr_cap = need_rr;
   }
-  if (p->path == 1 && p->rvec == nullptr) HIP_TRY(hipMalloc(&p->rvec, (size_t)p->m * sizeof(float)));
+  if (p->path == 1 && p->rvec == nullptr) HIP_TRY(hipMalloc(&p->rvec, (size_t)p->m * sizeof(double)));
   return FOS_OK;
 }
 
@@ -204,6 +206,12 @@ int prof_drain(fos_problem* p) {
 
 int prof_mark(fos_problem* p, bool start) {
   if (!p->profiling) return FOS_OK;
+  if (start) {
+    p->prof_open = (p->prof_seq++ % p->profiling) == 0;
+    if (!p->prof_open) return FOS_OK;
+  } else if (!p->prof_open) {
+    return FOS_OK;
+  }
   if (start && p->ev_used + 2 > p->ev_pool.size()) {
     if (p->ev_pool.size() >= 8192) {          // bounded pool: fold what we have (synchronises)
       int rc = prof_drain(p);
@@ -362,7 +370,9 @@ int fos_problem_create(fos_problem** out, const void* A, int64_t m, int64_t n, i
 
 int fos_problem_profile(fos_problem* p, int enable) {
   if (!p) return fail(FOS_ERR_ARG, "fos_problem_profile: null");
-  p->profiling = enable != 0;
+  p->profiling = enable > 0 ? enable : 0;
+  p->prof_seq = 0;
+  p->prof_open = false;
   return FOS_OK;
 }
 
@@ -426,8 +436,20 @@ int fos_gemv_pair(fos_problem* p, const float* y, float alpha2, float* grad, dou
   int n_rr = 0;
   if ((rc = launch_pass(p, ys, p->b, true, &n_rr))) return rc;
   if ((rc = launch_slab_reduce(p, n_rr, p->gbuf, rr_out, nullptr))) return rc;
-  hipLaunchKernelGGL(fos::add_l2_kernel, dim3(grid_1d(p->n, 256, 1024)), dim3(256), 0, p->stream, p->gbuf, alpha2, ya,
-                     grad, p->n);
+  hipLaunchKernelGGL(fos::add_l2_kernel<float>, dim3(grid_1d(p->n, 256, 1024)), dim3(256), 0, p->stream, p->gbuf,
+                     (double)alpha2, ya, grad, p->n);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
+int fos_gemv_pair_f64(fos_problem* p, const double* y, double alpha2, float* grad, double* rr_out) {
+  if (!p || !y || !grad) return fail(FOS_ERR_ARG, "fos_gemv_pair_f64: null");
+  YSource ys{nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, y};
+  int n_rr = 0, rc;
+  if ((rc = launch_pass(p, ys, p->b, true, &n_rr))) return rc;
+  if ((rc = launch_slab_reduce(p, n_rr, p->gbuf, rr_out, nullptr))) return rc;
+  hipLaunchKernelGGL(fos::add_l2_kernel<double>, dim3(grid_1d(p->n, 256, 1024)), dim3(256), 0, p->stream, p->gbuf, alpha2,
+                     y, grad, p->n);
   LAUNCH_CHECK();
   return FOS_OK;
 }
@@ -812,7 +834,24 @@ int fos_lbfgs_two_loop(const float* g, const float* S, const float* Y, int hist,
 
 int fos_vec_stats(const float* x, const float* g, const float* d, int64_t n, double* out4, void* stream) {
   if (!out4 || n <= 0) return fail(FOS_ERR_ARG, "fos_vec_stats: bad argument");
-  hipLaunchKernelGGL(fos::vec_stats_kernel, dim3(1), dim3(fos::LB_THREADS), 0, (hipStream_t)stream, x, g, d, n, out4);
+  hipLaunchKernelGGL(fos::vec_stats_kernel<float>, dim3(1), dim3(fos::LB_THREADS), 0, (hipStream_t)stream, x, g, d, n,
+                     out4);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
+int fos_vec_stats_f64(const double* x, const float* g, const float* d, int64_t n, double* out4, void* stream) {
+  if (!out4 || n <= 0) return fail(FOS_ERR_ARG, "fos_vec_stats_f64: bad argument");
+  hipLaunchKernelGGL(fos::vec_stats_kernel<double>, dim3(1), dim3(fos::LB_THREADS), 0, (hipStream_t)stream, x, g, d, n,
+                     out4);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
+int fos_vec_axpby_f64(double a, const double* x, double b, const float* y, double* out, int64_t n, void* stream) {
+  if (!x || !out || n <= 0 || (b != 0.0 && !y)) return fail(FOS_ERR_ARG, "fos_vec_axpby_f64: bad argument");
+  hipLaunchKernelGGL(fos::vec_axpby_f64_kernel, dim3(grid_1d(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, a, x, b,
+                     b != 0.0 ? y : nullptr, out, n);
   LAUNCH_CHECK();
   return FOS_OK;
 }

@@ -25,6 +25,8 @@ namespace fos {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+__device__ inline double form_y(double xc, double xp, double beta) { return xc + beta * (xc - xp); }
+
 // Where the kernel takes y from.  The FISTA iterate state (x_k, x_{k-1}) is kept in fp64 on the device: the
 // n-vectors are negligible traffic, and an fp32 state alone costs 1e-4 of parity on ill-conditioned data
 // (DESIGN.md "Precision").  y_k = x_k + beta (x_k - x_prev) is formed in fp64 and rounded ONCE to fp32 for the
@@ -36,13 +38,20 @@ struct YSource {
   const double* beta;    // device scalar, or nullptr: use beta_val (host-driven momentum, see fos_fista_run)
   const int* stopped;    // device flag: non-zero -> kernel is a no-op (solver already stopped)
   double beta_val;
+  const double* yd;      // explicit y in fp64 (L-BFGS iterate); used when y == nullptr and x_cur == nullptr
 };
 
 __device__ inline double source_beta(const YSource& ys) {
-  return ys.y != nullptr ? 0.0 : (ys.beta != nullptr ? *ys.beta : ys.beta_val);
+  return (ys.y != nullptr || ys.x_cur == nullptr) ? 0.0 : (ys.beta != nullptr ? *ys.beta : ys.beta_val);
+}
+// y_j in fp64 whatever the source
+__device__ inline double source_y(const YSource& ys, int64_t j, double beta) {
+  if (ys.y != nullptr) return (double)ys.y[j];
+  if (ys.x_cur != nullptr) return form_y(ys.x_cur[j], ys.x_prev[j], beta);
+  return ys.yd[j];
 }
 
-__device__ inline double form_y(double xc, double xp, double beta) { return xc + beta * (xc - xp); }
+
 
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<float> {
@@ -137,8 +146,7 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
         } else {
           // same form_y as the update kernel -> both kernels see the same y_k
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            yv[c][4 * q + e] = (float)form_y(ys.x_cur[col + 4 * q + e], ys.x_prev[col + 4 * q + e], beta);
+          for (int e = 0; e < 4; ++e) yv[c][4 * q + e] = (float)source_y(ys, col + 4 * q + e, beta);
         }
       }
     }
@@ -275,7 +283,7 @@ template <> __device__ inline float elem_to_float<bf16_t>(bf16_t v) { return __u
 template <typename T>
 __global__ __launch_bounds__(256) void residual_rows_kernel(const T* __restrict__ A, int64_t lda,
                                                            const float* __restrict__ b, int64_t m, int n,
-                                                           YSource ys, float* __restrict__ r_out,
+                                                           YSource ys, double* __restrict__ r_out,
                                                            double* __restrict__ rr_part) {
   if (ys.stopped != nullptr && *ys.stopped != 0) return;
   __shared__ double wsum[4];
@@ -285,15 +293,10 @@ __global__ __launch_bounds__(256) void residual_rows_kernel(const T* __restrict_
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < m; row += (int64_t)gridDim.x * 4) {
     const T* ar = A + row * lda;
     double acc = 0.0;
-    for (int j = lane; j < n; j += 64) {
-      float yj;
-      if (ys.y != nullptr) yj = ys.y[j];
-      else yj = (float)form_y(ys.x_cur[j], ys.x_prev[j], beta);
-      acc += (double)elem_to_float<T>(ar[j]) * (double)yj;
-    }
+    for (int j = lane; j < n; j += 64) acc += (double)elem_to_float<T>(ar[j]) * source_y(ys, j, beta);   // y kept in fp64
     acc = wave_sum(acc);
     if (b != nullptr) acc -= (double)b[row];
-    if (lane == 0) r_out[row] = (float)acc;
+    if (lane == 0) r_out[row] = acc;
     rr += acc * acc;
   }
   if (lane == 0) wsum[wave] = rr;
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(256) void residual_rows_kernel(const T* __restrict_
 // grid = (ceil(n/256), nchunks): block (cx, cy) sums rows of chunk cy for 256 columns -> slab[cy].
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_rows_kernel(const T* __restrict__ A, int64_t lda, int64_t m, int n,
-                                                            const float* __restrict__ r, const int* stopped,
+                                                            const double* __restrict__ r, const int* stopped,
                                                             int64_t rows_per_chunk, float* __restrict__ slabs) {
   if (stopped != nullptr && *stopped != 0) return;
   const int j = blockIdx.x * 256 + threadIdx.x;
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(256) void transpose_rows_kernel(const T* __restrict
   if (hi > m) hi = m;
   if (j >= n) return;
   double acc = 0.0;
-  for (int64_t row = lo; row < hi; ++row) acc += (double)elem_to_float<T>(A[row * lda + j]) * (double)r[row];
+  for (int64_t row = lo; row < hi; ++row) acc += (double)elem_to_float<T>(A[row * lda + j]) * r[row];
   slabs[(int64_t)blockIdx.y * n + j] = (float)acc;
 }
 

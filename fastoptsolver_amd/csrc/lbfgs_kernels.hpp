@@ -162,8 +162,9 @@ __global__ __launch_bounds__(LB_THREADS) void lbfgs_two_loop_kernel(const float*
   }
 }
 
-// out4 = { x.x, g.d, d.d, max|g| }; any pointer may be NULL (its entries are then 0).
-__global__ __launch_bounds__(LB_THREADS) void vec_stats_kernel(const float* __restrict__ x, const float* __restrict__ g,
+// out4 = { x.x, g.d, d.d, max|g| }; any pointer may be NULL (its entries are then 0).  XT: float or double iterate.
+template <typename XT>
+__global__ __launch_bounds__(LB_THREADS) void vec_stats_kernel(const XT* __restrict__ x, const float* __restrict__ g,
                                                                const float* __restrict__ d, int64_t n,
                                                                double* __restrict__ out4) {
   __shared__ double lds[4][16];
@@ -219,11 +220,23 @@ __global__ __launch_bounds__(256) void cast_f64_f32_kernel(const double* __restr
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = (float)in[i];
 }
 
-// grad_out = gbuf + alpha2 * y   (L-BFGS fg: lbfgs.py:50-51)
-__global__ __launch_bounds__(256) void add_l2_kernel(const float* __restrict__ gbuf, float alpha2,
-                                                     const float* __restrict__ y, float* __restrict__ out, int64_t n) {
+// grad_out = gbuf + alpha2 * y   (L-BFGS fg: lbfgs.py:50-51).  YT: float or double iterate.
+template <typename YT>
+__global__ __launch_bounds__(256) void add_l2_kernel(const float* __restrict__ gbuf, double alpha2,
+                                                     const YT* __restrict__ y, float* __restrict__ out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    out[i] = alpha2 != 0.f ? fmaf(alpha2, y[i], gbuf[i]) : gbuf[i];
+    out[i] = alpha2 != 0.0 ? (float)((double)gbuf[i] + alpha2 * (double)y[i]) : gbuf[i];
+}
+
+// out (fp64) = a*x (fp64) + b*y (fp32): the L-BFGS trial point x_old + stp*d with the iterate kept in fp64.
+__global__ __launch_bounds__(256) void vec_axpby_f64_kernel(double a, const double* __restrict__ x, double b,
+                                                            const float* __restrict__ y, double* __restrict__ out,
+                                                            int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    double v = a * x[i];
+    if (y != nullptr) v += b * (double)y[i];
+    out[i] = v;
+  }
 }
 
 }  // namespace fos

@@ -5,7 +5,8 @@ m=10, factr=1e7, maxls=20).  Here the unbounded L-BFGS-B iteration is restated n
 single-pass GEMV-pair kernel (K2), the direction is the one-launch two-loop kernel (K4), the line search moves
 only scalars over the host (``_linesearch.py``) while its vector updates are device kernels.
 
-fp32 note (SURVEY.md §7 "L-BFGS in fp32"): vectors are float32, all dots/loss accumulate in float64.  The
+fp32 note (SURVEY.md §7 "L-BFGS in fp32"): the iterate x is float64 on the device (like the FISTA state), the
+gradient / direction / history vectors are float32, all dots and the loss accumulate in float64.  The
 ``factr`` test (2.2e-9 relative) is below float32 resolution, so the search can hit its noise floor a few
 iterations before SciPy's float64 run stops; a line search that can make no further progress is treated as
 convergence, exactly as L-BFGS-B treats its own ABNORMAL_TERMINATION_IN_LNSRCH.
@@ -62,13 +63,17 @@ class LBFGSSolver:
         self.iterates_ = []
 
         def fg(x, d):
-            """loss, grad (device), and the scalars g.d, d.d, max|g| in one host read.   lbfgs.py:43-54"""
+            """loss, grad (device), and the scalars g.d, d.d, max|g| in one host read.   lbfgs.py:43-54
+            x is the fp64 iterate; the pass over A sees it rounded once to fp32 (kept in fp64 on the two-pass path)."""
             ev = gtimer.start()
-            g = prob.gemv_pair(x, a2, rr_out=rr_dev)
+            g = torch.empty(n, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.fos_gemv_pair_f64(prob.h, _core.ptr(x), a2, _core.ptr(g), _core.ptr(rr_dev)),
+                           "fos_gemv_pair_f64")
             gtimer.stop(ev)
             with torch.cuda.device(dev):
-                _lib.check(lib.fos_vec_stats(_core.ptr(x), _core.ptr(g), _core.ptr(d), n, _core.ptr(stats),
-                                             _core.stream_ptr()), "fos_vec_stats")
+                _lib.check(lib.fos_vec_stats_f64(_core.ptr(x), _core.ptr(g), _core.ptr(d), n, _core.ptr(stats),
+                                                 _core.stream_ptr()), "fos_vec_stats_f64")
             h = stats[:5].cpu().tolist()
             self.nfev_ += 1
             loss = 0.5 * h[4] + 0.5 * a2 * h[0]
@@ -85,7 +90,14 @@ class LBFGSSolver:
             self.iterates_.append(_core.from_device_vec(xk, like))
             self.history_.append(compute_objective(xk, prob, None, self.reg_type, self.alpha1, self.alpha2))
 
-        x = torch.zeros(n, dtype=torch.float32, device=dev)                          # lbfgs.py:63
+        def step_to(x_old, stp, d):
+            out = torch.empty(n, dtype=torch.float64, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.fos_vec_axpby_f64(1.0, _core.ptr(x_old), float(stp), _core.ptr(d), _core.ptr(out), n,
+                                                 _core.stream_ptr()), "fos_vec_axpby_f64")
+            return out
+
+        x = torch.zeros(n, dtype=torch.float64, device=dev)                          # lbfgs.py:63 (fp64 iterate)
         S = torch.zeros(_M, n, dtype=torch.float32, device=dev)
         Y = torch.zeros(_M, n, dtype=torch.float32, device=dev)
         hist, head = 0, 0
@@ -114,7 +126,7 @@ class LBFGSSolver:
                 if evals >= _MAXLS:
                     failed = True
                     break
-                x = vec_axpby(1.0, x_old, stp, d)
+                x = step_to(x_old, stp, d)
                 f, g, gd1, _, gmax = fg(x, d)
                 evals += 1
                 stp_used = stp

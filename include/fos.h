@@ -81,8 +81,9 @@ int fos_problem_tune(fos_problem* p, int threads, int chunks, int rows, int work
  * torch tensor that torch.distributed all-reduces between fos_fista_grad and fos_fista_update. */
 int fos_problem_set_gbuf(fos_problem* p, float* gbuf);
 
-/* Kernel timing for roofline reports: while enabled, every launch of the fused single-pass kernel (or of the
- * two fallback kernels) is bracketed by a pair of hipEvents recorded on the handle's stream.
+/* Kernel timing for roofline reports: while enabled (enable = N > 0), every N-th launch of the single-pass kernel
+ * (or of the two fallback kernels, or of the batched MFMA pass) is bracketed by a pair of hipEvents recorded on the
+ * handle's stream; N > 1 keeps the markers from perturbing the run being measured.
  * fos_problem_profile_read synchronises, returns the accumulated device milliseconds and the number of
  * bracketed launches since the last read, and resets both. */
 int fos_problem_profile(fos_problem* p, int enable);
@@ -91,6 +92,10 @@ int fos_problem_profile_read(fos_problem* p, double* ms_total, int64_t* launches
 /* K2: grad = A^T (A y - b) + alpha2*y ; *rr_out (device double, may be NULL) = ||A y - b||^2.
  * Replaces iterative_solvers.py:54, :173-175, :292-294 and lbfgs.py:46-51.  A is read ONCE. */
 int fos_gemv_pair(fos_problem* p, const float* y, float alpha2, float* grad, double* rr_out);
+
+/* The same with the iterate y given in fp64 (n doubles): the L-BFGS driver keeps x in fp64 like the FISTA state;
+ * y is rounded once to fp32 for the pass over A on the fused path and kept in fp64 on the two-pass path. */
+int fos_gemv_pair_f64(fos_problem* p, const double* y, double alpha2, float* grad, double* rr_out);
 
 /* K5: out3 (device doubles) = { ||A x - b||^2, ||x||_2^2, ||x||_1 } — one pass over A.
  * Replaces g_smooth iterative_solvers.py:163-168 and compute_objective objective_functions.py:13-24. */
@@ -154,6 +159,9 @@ int fos_lbfgs_two_loop(const float* g, const float* S, const float* Y, int hist,
 int fos_vec_stats(const float* x, const float* g, const float* d, int64_t n, double* out4, void* stream);
 /* out = a*x + b*y (y may be NULL when b == 0). */
 int fos_vec_axpby(double a, const float* x, double b, const float* y, float* out, int64_t n, void* stream);
+/* fp64-iterate forms: x and out in fp64, g / d / y in fp32. */
+int fos_vec_stats_f64(const double* x, const float* g, const float* d, int64_t n, double* out4, void* stream);
+int fos_vec_axpby_f64(double a, const double* x, double b, const float* y, double* out, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -493,15 +493,17 @@ def test_batched_and_sequential_line_search_agree(fos):
 
 
 def test_lbfgs_boston_end_point(fos):
-    """Config-1 data through L-BFGS.  cond(A^T A) ~ 1e9: with float32 vectors the PATH differs from SciPy's float64
-    run after the second iterate (curvature pairs are differences of noisy gradients), the END POINT does not."""
+    """Config-1 data through L-BFGS.  cond(A^T A) ~ 1e9: with a float32 gradient the PATH drifts from SciPy's float64
+    run in the middle iterations (curvature pairs are differences of noisy gradients; even two float64 codes differ
+    by 1e-5 there, tests/test_oracle_golden.py), the iteration count and the END POINT agree."""
     fx = _data.load("boston")
     A, b = fx["boston/A"], fx["boston/b"]
     s = fos.LBFGSSolver("ridge", 0.0, 0.5).fit(A, b)
     # SURVEY 8(c) known answer of the reference for this call
     assert np.allclose(s.x_, [5.04537675, 0.14409563, -0.01939221, -0.05905357, 1.53772434], rtol=2e-4, atol=2e-5)
     assert s.final_obj_ == pytest.approx(2077.060367882381, rel=1e-6)
-    assert _data.rel(s.x_, fx["boston/lbfgs/enet_tiny1/x"]) < 5e-5
+    assert _data.rel(s.x_, fx["boston/lbfgs/enet_tiny1/x"]) < 1e-5
+    assert abs(s.nit_ - len(fx["boston/lbfgs/enet_tiny1/iterates"])) <= 2 and abs(s.nfev_ - 33) <= 4   # SURVEY 8c: 23 / 33
     assert s.task_.startswith("CONVERGENCE")
     assert _data.rel(s.iterates_[0], fx["boston/lbfgs/enet_tiny1/iterates"][0]) < 1e-6     # first step identical
 

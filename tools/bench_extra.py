@@ -85,7 +85,7 @@ def main():
     torch.cuda.synchronize()
     best = min(timed_us(lambda: st.run(50), 1) / 50 for _ in range(3))
     bi = bytes_per_iter(cfg["m"], cfg["n"], "bf16")
-    prob.profile(True)
+    prob.profile(1)
     prob.profile_read()
     st.run(50)
     ms, cnt = prob.profile_read()

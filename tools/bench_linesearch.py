@@ -31,7 +31,7 @@ for batch in (True, False):
 # bare kernel time of the batched pass
 X = torch.randn(cfg["n"], 16, device="cuda")
 prob.residual_batch(X)
-prob.profile(True); prob.profile_read()
+prob.profile(1); prob.profile_read()
 for _ in range(20):
     prob.residual_batch(X)
 ms, cnt = prob.profile_read()

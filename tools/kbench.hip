@@ -81,13 +81,14 @@ int main(int argc, char** argv) {
   printf("device %s  CUs %d  m %lld n %d  A %.2f GiB\n", prop.name, prop.multiProcessorCount, (long long)m, n,
          (double)m * n * 4 / (1 << 30));
   const int ncu = prop.multiProcessorCount;
-  float *A, *b, *y, *slabs, *g, *gref, *rvec;
+  float *A, *b, *y, *slabs, *g, *gref;
+  double* rvec;
   double* rr;
   const int max_wg = 4096;
   CK(hipMalloc(&A, (size_t)m * n * 4));
   CK(hipMalloc(&b, (size_t)m * 4));
   CK(hipMalloc(&y, (size_t)n * 4));
-  CK(hipMalloc(&rvec, (size_t)m * 4));
+  CK(hipMalloc(&rvec, (size_t)m * 8));
   CK(hipMalloc(&slabs, (size_t)max_wg * n * 4));
   CK(hipMalloc(&g, (size_t)n * 4));
   CK(hipMalloc(&gref, (size_t)n * 4));
@@ -101,7 +102,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  fos::YSource ys{y, nullptr, nullptr, nullptr, nullptr};
+  fos::YSource ys{y, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr};
   unsigned short* A16 = nullptr;
   if (bf16) {
     CK(hipMalloc(&A16, (size_t)m * n * 2));
