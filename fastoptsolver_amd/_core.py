@@ -218,6 +218,23 @@ class Fista:
         with torch.cuda.device(self.prob.device):
             _lib.check(self.lib.fos_fista_run(self.h, int(iters)), "fos_fista_run")
 
+    def run_history(self, iters):
+        """Device-resident history run: (x_hist [iters, n] float64, hist [iters, 4] float64 =
+        {||Ax-b||^2, ||x||_1, ||x||_2^2, ||dx||^2}) as device tensors, or None when this solver configuration /
+        problem shape needs the host-driven loop."""
+        dev = self.prob.device
+        xh = torch.empty(iters, self.prob.n, dtype=torch.float64, device=dev)
+        hist = torch.empty(iters, 4, dtype=torch.float64, device=dev)
+        nbytes = self.lib.fos_fista_history_workspace(self.h, int(iters))
+        work = torch.empty(max(1, (nbytes + 7) // 8), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            rc = self.lib.fos_fista_run_history(self.h, int(iters), ptr(xh), ptr(hist), ptr(work))
+        if rc == -4:
+            return None
+        _lib.check(rc, "fos_fista_run_history")
+        self._keep = work            # stays alive until the stream has consumed it (next sync)
+        return xh, hist
+
     def grad(self, dual=False):
         """Gradient pass at y_k; dual=True also leaves ||A x_k - b||^2 in status().rr_x (same pass over A)."""
         with torch.cuda.device(self.prob.device):

@@ -630,16 +630,90 @@ static void host_momentum(const fos::FistaParams& prm, long long k, double* t, d
   }
 }
 
-static void launch_update_from_slabs(fos_fista* f, double* part, int host_beta, double beta_val) {
+static void launch_update_from_slabs(fos_fista* f, double* part, int host_beta, double beta_val,
+                                     double* x_hist = nullptr) {
   fos_problem* p = f->p;
   if (p->vec4)
     hipLaunchKernelGGL((fos::fista_update_kernel<true, true>), dim3(f->nupd), dim3(256), 0, p->stream, p->slabs,
                        p->nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
-                       beta_val);
+                       beta_val, x_hist);
   else
     hipLaunchKernelGGL((fos::fista_update_kernel<true, false>), dim3(f->nupd), dim3(256), 0, p->stream, p->slabs,
                        p->nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
-                       beta_val);
+                       beta_val, x_hist);
+}
+
+static bool plain_run(const fos_fista* f) {
+  return !(f->prm.mode == fos::MODE_FISTA && f->prm.adaptive_restart) && f->prm.tol_step == 0.0 &&
+         f->prm.tol_ratio == 0.0;
+}
+
+static int refresh_host_scalars(fos_fista* f, bool* stopped) {
+  *stopped = false;
+  if (f->host_valid) return FOS_OK;
+  fos_fista_status st;
+  int rc = fos_fista_status_get(f, &st);      // synchronises once after split-mode / device-driven calls
+  if (rc) return rc;
+  *stopped = st.stopped != FOS_STOP_NONE;
+  f->h_t = st.t_prev; f->h_beta = st.beta; f->h_k = st.k;
+  f->host_valid = true;
+  return FOS_OK;
+}
+
+int64_t fos_fista_history_workspace(fos_fista* f, int iters) {
+  if (!f || iters < 0) return -1;
+  return ((int64_t)(iters + 1) * f->p->nwg + (int64_t)iters * f->nupd * 4) * (int64_t)sizeof(double);
+}
+
+int fos_fista_run_history(fos_fista* f, int iters, double* x_hist, double* hist, void* work) {
+  if (!f || iters < 0 || (iters > 0 && (!x_hist || !hist || !work)))
+    return fail(FOS_ERR_ARG, "fos_fista_run_history: bad argument");
+  fos_problem* p = f->p;
+  if (!plain_run(f) || p->path != 0 || p->entry->dual == nullptr)
+    return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_history: needs a plain run on the fused path with a DUAL kernel");
+  if (iters == 0) return FOS_OK;
+  bool stopped = false;
+  int rc = refresh_host_scalars(f, &stopped);
+  if (rc) return rc;
+  if (stopped) return fail(FOS_ERR_STATE, "fos_fista_run_history: solver already stopped");
+  const int nwg = p->nwg;
+  double* rr2_slots = reinterpret_cast<double*>(work);                 // (iters + 1) x nwg
+  double* part_slots = rr2_slots + (size_t)(iters + 1) * nwg;          // iters x nupd x 4
+  double* saved_rr2 = p->rr2_part;
+  int n_rr = 0;
+  for (int it = 0; it < iters; ++it) {
+    YSource ys{nullptr, f->x_cur, f->x_prev, nullptr, &f->scal->stopped, f->h_beta};
+    p->rr2_part = rr2_slots + (size_t)it * nwg;                        // slot it = residual of the iterate BEFORE it
+    rc = launch_pass(p, ys, p->b, true, &n_rr, true);
+    p->rr2_part = saved_rr2;
+    if (rc) return rc;
+    launch_update_from_slabs(f, part_slots + (size_t)it * f->nupd * 4, 1, f->h_beta, x_hist + (size_t)it * p->n);
+    LAUNCH_CHECK();
+    host_momentum(f->prm, f->h_k, &f->h_t, &f->h_beta);
+    f->h_k += 1;
+  }
+  // closing residual pass: ||A x_last - b||^2 -> slot iters (written by the residual-only kernel into rr_part)
+  hipLaunchKernelGGL(fos::cast_f64_f32_kernel, dim3(grid_1d(p->n, 256, 1024)), dim3(256), 0, p->stream, f->x_cur, p->ybuf,
+                     p->n);
+  LAUNCH_CHECK();
+  {
+    YSource ys{p->ybuf, nullptr, nullptr, nullptr, nullptr};
+    double* saved_rr = p->rr_part;
+    p->rr_part = rr2_slots + (size_t)iters * nwg;
+    rc = launch_pass(p, ys, p->b, false, &n_rr);
+    p->rr_part = saved_rr;
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(fos::history_fold_kernel, dim3(iters), dim3(64), 0, p->stream, rr2_slots, nwg, part_slots, f->nupd,
+                     hist);
+  LAUNCH_CHECK();
+  // device scalars: step norms of the last two iterations, momentum from the host
+  const double* cur = part_slots + (size_t)(iters - 1) * f->nupd * 4;
+  const double* prev = iters >= 2 ? part_slots + (size_t)(iters - 2) * f->nupd * 4 : nullptr;
+  hipLaunchKernelGGL(fos::fista_finalize_plain_kernel, dim3(1), dim3(64), 0, p->stream, cur, prev, f->nupd, p->rr_part,
+                     nwg, f->scal, f->h_t, f->h_beta, f->h_k);
+  LAUNCH_CHECK();
+  return FOS_OK;
 }
 
 int fos_fista_run(fos_fista* f, int iters) {
@@ -649,17 +723,11 @@ int fos_fista_run(fos_fista* f, int iters) {
   // Plain run: no data-dependent control (adaptive restart / stopping tolerances).  t_k and beta_k are then a fixed
   // sequence: the host passes beta_k to both kernels by value, and the scalar bookkeeping kernel runs once per call
   // instead of once per iteration (two launches per iteration instead of three).
-  const bool plain = !(f->prm.mode == fos::MODE_FISTA && f->prm.adaptive_restart) && f->prm.tol_step == 0.0 &&
-                     f->prm.tol_ratio == 0.0;
-  if (plain) {
-    if (!f->host_valid) {
-      fos_fista_status st;
-      int rc = fos_fista_status_get(f, &st);      // synchronises once after split-mode / device-driven calls
-      if (rc) return rc;
-      if (st.stopped != FOS_STOP_NONE) return FOS_OK;
-      f->h_t = st.t_prev; f->h_beta = st.beta; f->h_k = st.k;
-      f->host_valid = true;
-    }
+  if (plain_run(f)) {
+    bool stopped = false;
+    int rc0 = refresh_host_scalars(f, &stopped);
+    if (rc0) return rc0;
+    if (stopped) return FOS_OK;
     const size_t psz = (size_t)f->nupd * 4;
     int n_rr = 0;
     for (int it = 0; it < iters; ++it) {

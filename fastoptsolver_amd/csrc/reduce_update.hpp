@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256) void fista_update_kernel(const float* __restri
                                                           const float* __restrict__ gbuf, int n,
                                                           double* __restrict__ x_cur, double* __restrict__ x_prev,
                                                           const FistaScalars* __restrict__ scal, FistaParams prm,
-                                                          double* __restrict__ part, int host_beta, double beta_val) {
+                                                          double* __restrict__ part, int host_beta, double beta_val,
+                                                          double* __restrict__ x_hist = nullptr) {
   if (scal->stopped != 0) return;
   __shared__ f32x4 lds[RG][RQ];
   __shared__ double dl[4 * 4];
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(256) void fista_update_kernel(const float* __restri
     acc[3] += xn * xn;
     x_prev[col + e] = xc;
     x_cur[col + e] = xn;
+    if (x_hist != nullptr) x_hist[col + e] = xn;      // device-resident history (fos_fista_run_history)
   }
   block_sum_256<4>(acc, dl);
   if (threadIdx.x == 0) {
@@ -320,10 +322,36 @@ __global__ __launch_bounds__(64) void fista_finalize_plain_kernel(const double* 
   scal->gnorm2 = s[1];
   scal->xnorm1 = s[2];
   scal->xnorm2 = s[3];
-  scal->rr = rr;
+  if (n_rr > 0) scal->rr = rr;
   scal->t_prev = t_prev;
   scal->beta = beta_next;
   scal->k = k_total;
+}
+
+// History fold (fos_fista_run_history): block i turns the raw partials of iteration i into
+// hist[i] = { ||A x_{i+1} - b||^2, ||x_{i+1}||_1, ||x_{i+1}||_2^2, ||x_{i+1} - x_i||^2 }.
+// rr2 partials of slot i+1 belong to the iterate produced by iteration i (slot `iters` = the closing residual pass).
+__global__ __launch_bounds__(64) void history_fold_kernel(const double* __restrict__ rr2_slots, int n_rr,
+                                                         const double* __restrict__ part_slots, int nparts,
+                                                         double* __restrict__ hist) {
+  const int i = blockIdx.x;
+  const double* rr2 = rr2_slots + (int64_t)(i + 1) * n_rr;
+  const double* part = part_slots + (int64_t)i * nparts * 4;
+  double rr = 0.0, s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int j = threadIdx.x; j < n_rr; j += 64) rr += rr2[j];
+  for (int j = threadIdx.x; j < nparts; j += 64) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s[c] += part[j * 4 + c];
+  }
+  rr = wave_sum(rr);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) s[c] = wave_sum(s[c]);
+  if (threadIdx.x == 0) {
+    hist[i * 4 + 0] = rr;
+    hist[i * 4 + 1] = s[2];
+    hist[i * 4 + 2] = s[3];
+    hist[i * 4 + 3] = s[0];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -149,6 +149,25 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
             del grad_call_times[k:]
         return st
 
+    # History without any per-iteration host round trip: x and the objective ingredients are recorded on the device
+    # by the same two kernels of the plain run and read back once (ref:224-232, :319-322).
+    plain = not (mode == _lib.MODE_FISTA and adaptive_restart) and tol == 0.0 and tol_ratio == 0.0
+    if history is not None and log is None and not backtracking and plain and max_iter > 0:
+        ev = gtimer.start()
+        rec = st.run_history(max_iter)
+        if rec is not None:
+            gtimer.stop(ev, max_iter)
+            xh, hs = rec
+            hs = hs.cpu().numpy()
+            if like.tensor:
+                history["x"].extend(_core.from_device_vec(xh[i], like) for i in range(max_iter))
+            else:
+                history["x"].extend(list(xh.cpu().numpy()))
+            history["obj"].extend(history_obj(float(r[0]), float(r[2]), float(r[1])) for r in hs)
+            gtimer.flush()
+            return st
+        gtimer.pending.clear()
+
     # History objective f(x_k) without the reference's extra pass per iteration (ref:225-230, :321): the DUAL
     # gradient pass of iteration k also returns ||A x_k - b||^2, so f(x_k) is appended one iteration late and only
     # the very last iterate needs a residual pass of its own.

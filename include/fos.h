@@ -125,6 +125,15 @@ int fos_fista_set_tau(fos_fista* f, double tau);
 /* Enqueue `iters` full iterations (gradient, prox, momentum, restart and stop logic all on the device;
  * no host round trip).  Iterations after a device-side stop are no-ops.  :170-242, :289-342 */
 int fos_fista_run(fos_fista* f, int iters);
+/* Plain run that also records the history on the device (return_history=True of fista :224-232 / fista_delta
+ * :319-322 without a host round trip per iteration and without the reference's extra pass over A per iteration):
+ *   x_hist   iters x n doubles: row i = iterate after iteration i
+ *   hist     iters x 4 doubles: { ||A x - b||^2, ||x||_1, ||x||_2^2, ||x - x_before||^2 } of that iterate
+ *   work     scratch of fos_fista_history_workspace(f, iters) bytes (caller-owned device memory)
+ * Only for runs without data-dependent control (no adaptive restart, no stopping tolerance) on the fused path with a
+ * DUAL kernel; otherwise FOS_ERR_UNSUPPORTED and the caller drives the split form below.  Enqueues only. */
+int64_t fos_fista_history_workspace(fos_fista* f, int iters);
+int fos_fista_run_history(fos_fista* f, int iters, double* x_hist, double* hist, void* work);
 /* Split form for host-driven control (grad-norm stop :179, backtracking :183-197, sharded runs):
  *   fos_fista_grad    gbuf[0..n) = A^T (A y_k - b) (WITHOUT alpha2*y), gbuf[n] = ||A y_k - b||^2 (float)
  *   fos_fista_update  prox + momentum from gbuf (after an optional all-reduce of gbuf[0..n]) */
