@@ -68,7 +68,7 @@ const MenuEntry kMenu[] = {
     ENTRY_NB(FOS_F32, float, 512, 4, 2, 2, 3),   ENTRY_D(FOS_F32, float, 512, 8, 1, 2),  ENTRY(FOS_F32, float, 512, 8, 2, 2),
     ENTRY(FOS_F32, float, 1024, 4, 1, 4),  ENTRY(FOS_F32, float, 1024, 2, 2, 4),
     ENTRY(FOS_BF16, fos::bf16_t, 256, 1, 4, 2), ENTRY(FOS_BF16, fos::bf16_t, 256, 2, 2, 2),
-    ENTRY(FOS_BF16, fos::bf16_t, 256, 4, 2, 2), ENTRY(FOS_BF16, fos::bf16_t, 1024, 2, 2, 4),
+    ENTRY(FOS_BF16, fos::bf16_t, 256, 4, 2, 2), ENTRY_NB(FOS_BF16, fos::bf16_t, 512, 4, 1, 2, 4),
     ENTRY(FOS_BF16, fos::bf16_t, 512, 4, 2, 2),
 };
 
@@ -141,6 +141,10 @@ struct fos_fista {
   double h_t = 1.0, h_beta = 0.0;
   long long h_k = 0;
   double* part2 = nullptr;           // ping-pong partials for plain runs: 2 * nupd * 4 doubles
+  float* ynext = nullptr;            // plain runs: y_{k+1} in fp32 written by the update kernel
+  bool y_valid = false;              // ynext holds y for iteration h_k
+  bool pending = false;              // plain split-mode updates whose scalar bookkeeping has not run yet
+  long long plain_count = 0;         // consecutive plain iterations whose partials sit in part2
   double *x_cur = nullptr, *x_prev = nullptr;   // fp64 iterate state
   float* dlt = nullptr;                         // trial difference vector x_tmp - y_k (fp32)
   fos::FistaScalars* scal = nullptr;
@@ -541,6 +545,7 @@ int fos_fista_create(fos_problem* p, fos_fista** out) {
   if (he == hipSuccess) he = hipMalloc(&f->out5, 8 * sizeof(double));
   f->nupd = (int)((p->n + fos::RCOLS - 1) / fos::RCOLS);
   if (he == hipSuccess) he = hipMalloc(&f->part2, (size_t)2 * f->nupd * 4 * sizeof(double));
+  if (he == hipSuccess) he = hipMalloc(&f->ynext, (size_t)p->n * sizeof(float));
   if (he != hipSuccess) {
     fos_fista_destroy(f);
     return fail(FOS_ERR_HIP, std::string("fos_fista_create: ") + hipGetErrorString(he));
@@ -551,7 +556,7 @@ int fos_fista_create(fos_problem* p, fos_fista** out) {
 
 int fos_fista_destroy(fos_fista* f) {
   if (!f) return FOS_OK;
-  void* bufs[] = {f->x_cur, f->x_prev, f->dlt, f->scal, f->out5, f->part2};
+  void* bufs[] = {f->x_cur, f->x_prev, f->dlt, f->scal, f->out5, f->part2, f->ynext};
   for (void* q : bufs)
     if (q) (void)hipFree(q);
   delete f;
@@ -592,6 +597,9 @@ int fos_fista_reset(fos_fista* f, const fos_fista_params* prm, const double* x0)
   HIP_TRY(hipMemcpyAsync(f->scal, &init, sizeof(init), hipMemcpyHostToDevice, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));   // `init` is a stack object
   f->host_valid = true;
+  f->y_valid = false;
+  f->pending = false;
+  f->plain_count = 0;
   f->h_t = 1.0;
   f->h_beta = 0.0;
   f->h_k = 0;
@@ -631,16 +639,39 @@ static void host_momentum(const fos::FistaParams& prm, long long k, double* t, d
 }
 
 static void launch_update_from_slabs(fos_fista* f, double* part, int host_beta, double beta_val,
-                                     double* x_hist = nullptr) {
+                                     double* x_hist = nullptr, float* y_next = nullptr, double beta_next = 0.0) {
   fos_problem* p = f->p;
   if (p->vec4)
     hipLaunchKernelGGL((fos::fista_update_kernel<true, true>), dim3(f->nupd), dim3(256), 0, p->stream, p->slabs,
                        p->nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
-                       beta_val, x_hist);
+                       beta_val, x_hist, y_next, beta_next);
   else
     hipLaunchKernelGGL((fos::fista_update_kernel<true, false>), dim3(f->nupd), dim3(256), 0, p->stream, p->slabs,
                        p->nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
-                       beta_val, x_hist);
+                       beta_val, x_hist, y_next, beta_next);
+}
+
+// y source of a plain-run iteration: the fp32 vector the previous update kernel wrote, or (first iteration after a
+// reset / split-mode call) the fp64 state with the host's beta.  Both give bit-identical y.
+static YSource plain_source(fos_fista* f) {
+  if (f->y_valid) return YSource{f->ynext, nullptr, nullptr, nullptr, &f->scal->stopped, 0.0, nullptr};
+  return YSource{nullptr, f->x_cur, f->x_prev, nullptr, &f->scal->stopped, f->h_beta, nullptr};
+}
+
+// Bring the device scalars up to date after plain split-mode updates (their bookkeeping is deferred so that a
+// sharded run pays two launches + one collective per iteration).  n_rr = 0: rr was written by slab_reduce.
+static int flush_pending(fos_fista* f) {
+  if (!f->pending) return FOS_OK;
+  fos_problem* p = f->p;
+  const size_t psz = (size_t)f->nupd * 4;
+  const long long last = f->h_k - 1;
+  const double* cur = f->part2 + (size_t)(last & 1) * psz;
+  const double* prev = f->plain_count >= 2 ? f->part2 + (size_t)((last - 1) & 1) * psz : nullptr;
+  hipLaunchKernelGGL(fos::fista_finalize_plain_kernel, dim3(1), dim3(64), 0, p->stream, cur, prev, f->nupd, p->rr_part, 0,
+                     f->scal, f->h_t, f->h_beta, f->h_k);
+  LAUNCH_CHECK();
+  f->pending = false;
+  return FOS_OK;
 }
 
 static bool plain_run(const fos_fista* f) {
@@ -681,8 +712,11 @@ int fos_fista_run_history(fos_fista* f, int iters, double* x_hist, double* hist,
   double* part_slots = rr2_slots + (size_t)(iters + 1) * nwg;          // iters x nupd x 4
   double* saved_rr2 = p->rr2_part;
   int n_rr = 0;
+  if ((rc = flush_pending(f))) return rc;
+  f->y_valid = false;      // the DUAL pass needs x_k itself, so it always rebuilds y from the fp64 state
+  f->plain_count = 0;
   for (int it = 0; it < iters; ++it) {
-    YSource ys{nullptr, f->x_cur, f->x_prev, nullptr, &f->scal->stopped, f->h_beta};
+    YSource ys{nullptr, f->x_cur, f->x_prev, nullptr, &f->scal->stopped, f->h_beta, nullptr};
     p->rr2_part = rr2_slots + (size_t)it * nwg;                        // slot it = residual of the iterate BEFORE it
     rc = launch_pass(p, ys, p->b, true, &n_rr, true);
     p->rr2_part = saved_rr2;
@@ -731,23 +765,28 @@ int fos_fista_run(fos_fista* f, int iters) {
     const size_t psz = (size_t)f->nupd * 4;
     int n_rr = 0;
     for (int it = 0; it < iters; ++it) {
-      YSource ys{nullptr, f->x_cur, f->x_prev, nullptr, &f->scal->stopped, f->h_beta};
       int rc;
-      if ((rc = launch_pass(p, ys, p->b, true, &n_rr))) return rc;
-      launch_update_from_slabs(f, f->part2 + (size_t)(f->h_k & 1) * psz, 1, f->h_beta);
+      if ((rc = launch_pass(p, plain_source(f), p->b, true, &n_rr))) return rc;
+      const double beta_k = f->h_beta;
+      host_momentum(f->prm, f->h_k, &f->h_t, &f->h_beta);          // beta_{k+1}
+      launch_update_from_slabs(f, f->part2 + (size_t)(f->h_k & 1) * psz, 1, beta_k, nullptr, f->ynext, f->h_beta);
       LAUNCH_CHECK();
-      host_momentum(f->prm, f->h_k, &f->h_t, &f->h_beta);
+      f->y_valid = true;
       f->h_k += 1;
+      f->plain_count += 1;
     }
+    f->pending = false;
     const long long last = f->h_k - 1;
     const double* cur = f->part2 + (size_t)(last & 1) * psz;
-    const double* prev = iters >= 2 ? f->part2 + (size_t)((last - 1) & 1) * psz : nullptr;
+    const double* prev = f->plain_count >= 2 ? f->part2 + (size_t)((last - 1) & 1) * psz : nullptr;
     hipLaunchKernelGGL(fos::fista_finalize_plain_kernel, dim3(1), dim3(64), 0, p->stream, cur, prev, f->nupd, p->rr_part,
                        n_rr, f->scal, f->h_t, f->h_beta, f->h_k);
     LAUNCH_CHECK();
     return FOS_OK;
   }
   f->host_valid = false;
+  f->y_valid = false;
+  f->plain_count = 0;
   for (int it = 0; it < iters; ++it) {
     int n_rr = 0, rc;
     if ((rc = launch_pass(p, fista_source(f), p->b, true, &n_rr))) return rc;
@@ -762,7 +801,8 @@ int fos_fista_grad(fos_fista* f) {
   if (!f) return fail(FOS_ERR_ARG, "fos_fista_grad: null");
   fos_problem* p = f->p;
   int n_rr = 0, rc;
-  if ((rc = launch_pass(p, fista_source(f), p->b, true, &n_rr))) return rc;
+  const YSource ys = (plain_run(f) && f->host_valid) ? plain_source(f) : fista_source(f);
+  if ((rc = launch_pass(p, ys, p->b, true, &n_rr))) return rc;
   return launch_slab_reduce(p, n_rr, p->gbuf, &f->scal->rr, &f->scal->stopped);
 }
 
@@ -770,6 +810,7 @@ int fos_fista_grad_dual(fos_fista* f) {
   if (!f) return fail(FOS_ERR_ARG, "fos_fista_grad_dual: null");
   fos_problem* p = f->p;
   int n_rr = 0, rc;
+  if ((rc = flush_pending(f))) return rc;
   if (p->path == 0 && p->entry->dual != nullptr) {
     if ((rc = launch_pass(p, fista_source(f), p->b, true, &n_rr, true))) return rc;
     if ((rc = launch_slab_reduce(p, n_rr, p->gbuf, &f->scal->rr, &f->scal->stopped))) return rc;
@@ -793,20 +834,46 @@ int fos_fista_grad_dual(fos_fista* f) {
 int fos_fista_update(fos_fista* f) {
   if (!f) return fail(FOS_ERR_ARG, "fos_fista_update: null");
   fos_problem* p = f->p;
+  const bool plain = plain_run(f) && f->host_valid;
+  double* part = p->part;
+  int host_beta = 0;
+  double beta_k = 0.0, beta_next = 0.0;
+  float* y_next = nullptr;
+  if (plain) {
+    // host-driven momentum (see fos_fista_run): no per-iteration bookkeeping launch, y handed on as one fp32 vector
+    beta_k = f->h_beta;
+    host_momentum(f->prm, f->h_k, &f->h_t, &f->h_beta);
+    beta_next = f->h_beta;
+    part = f->part2 + (size_t)(f->h_k & 1) * (size_t)f->nupd * 4;
+    host_beta = 1;
+    y_next = f->ynext;
+  }
   if (p->vec4)
     hipLaunchKernelGGL((fos::fista_update_kernel<false, true>), dim3(f->nupd), dim3(256), 0, p->stream,
-                       (const float*)nullptr, 0, p->gbuf, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, p->part, 0, 0.0);
+                       (const float*)nullptr, 0, p->gbuf, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
+                       beta_k, (double*)nullptr, y_next, beta_next);
   else
     hipLaunchKernelGGL((fos::fista_update_kernel<false, false>), dim3(f->nupd), dim3(256), 0, p->stream,
-                       (const float*)nullptr, 0, p->gbuf, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, p->part, 0, 0.0);
+                       (const float*)nullptr, 0, p->gbuf, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
+                       beta_k, (double*)nullptr, y_next, beta_next);
   LAUNCH_CHECK();
+  if (plain) {
+    f->h_k += 1;
+    f->plain_count += 1;
+    f->y_valid = true;
+    f->pending = true;
+    return FOS_OK;
+  }
   f->host_valid = false;
+  f->y_valid = false;
+  f->plain_count = 0;
   return launch_finalize(f, 0);
 }
 
 int fos_fista_trial(fos_fista* f, double t, int with_residual, double out8[8]) {
   if (!f || !out8 || !(t > 0.0)) return fail(FOS_ERR_ARG, "fos_fista_trial: bad argument");
   fos_problem* p = f->p;
+  { int rcf = flush_pending(f); if (rcf) return rcf; }
   const int grid = grid_1d(p->n, 256, 256);
   HIP_TRY(hipMemsetAsync(f->out5, 0, 8 * sizeof(double), p->stream));
   hipLaunchKernelGGL(fos::fista_trial_kernel, dim3(grid), dim3(256), 0, p->stream, p->gbuf, (int)p->n, f->x_cur,
@@ -831,6 +898,7 @@ int fos_fista_trial_batch(fos_fista* f, double t, double eta, int nv, double* ou
   if (!f || !out || !(t > 0.0) || !(eta > 0.0) || nv < 1 || nv > fos::BT_NV)
     return fail(FOS_ERR_ARG, "fos_fista_trial_batch: bad argument");
   fos_problem* p = f->p;
+  { int rcf = flush_pending(f); if (rcf) return rcf; }
   if (!batch_supported(p)) return fail(FOS_ERR_UNSUPPORTED, "fos_fista_trial_batch: needs the fused fp32 path");
   int rc = ensure_batch_workspace(p);
   if (rc) return rc;
@@ -860,6 +928,7 @@ int fos_fista_trial_batch(fos_fista* f, double t, double eta, int nv, double* ou
 
 int fos_fista_status_get(fos_fista* f, fos_fista_status* out) {
   if (!f || !out) return fail(FOS_ERR_ARG, "fos_fista_status_get: null");
+  { int rcf = flush_pending(f); if (rcf) return rcf; }
   fos::FistaScalars h;
   HIP_TRY(hipMemcpyAsync(&h, f->scal, sizeof(h), hipMemcpyDeviceToHost, f->p->stream));
   HIP_TRY(hipStreamSynchronize(f->p->stream));

@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256) void fista_update_kernel(const float* __restri
                                                           double* __restrict__ x_cur, double* __restrict__ x_prev,
                                                           const FistaScalars* __restrict__ scal, FistaParams prm,
                                                           double* __restrict__ part, int host_beta, double beta_val,
-                                                          double* __restrict__ x_hist = nullptr) {
+                                                          double* __restrict__ x_hist = nullptr,
+                                                          float* __restrict__ y_next = nullptr, double beta_next = 0.0) {
   if (scal->stopped != 0) return;
   __shared__ f32x4 lds[RG][RQ];
   __shared__ double dl[4 * 4];
@@ -214,6 +215,8 @@ __global__ __launch_bounds__(256) void fista_update_kernel(const float* __restri
     x_prev[col + e] = xc;
     x_cur[col + e] = xn;
     if (x_hist != nullptr) x_hist[col + e] = xn;      // device-resident history (fos_fista_run_history)
+    // plain runs: beta_{k+1} is known, hand the next A pass its y as ONE fp32 vector (same form_y, same rounding)
+    if (y_next != nullptr) y_next[col + e] = (float)form_y(xn, xc, beta_next);
   }
   block_sum_256<4>(acc, dl);
   if (threadIdx.x == 0) {

@@ -1,0 +1,33 @@
+"""CPU (compile only): no kernel of libfos_hip.so may spill registers or use scratch.  A menu geometry that starts
+spilling after an unrelated edit silently halves the bandwidth of that configuration (it happened to the bf16
+default in round 1: 84 % -> 46 % of the roofline), so this is checked at build level."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(600)
+def test_library_kernels_do_not_spill(tmp_path):
+    from fastoptsolver_amd import build
+    src = os.path.join(ROOT, "fastoptsolver_amd", "csrc", "fos_api.hip")
+    cmd = [build.hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-Rpass-analysis=kernel-resource-usage",
+           "-c", "-o", str(tmp_path / "x.o"), src]
+    out = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
+    kernels, cur = {}, None
+    for line in out.splitlines():
+        m = re.search(r"remark:\s+Function Name:\s+(\S+)", line)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = {}
+            continue
+        m = re.search(r"remark:\s+(VGPRs Spill|SGPRs Spill|ScratchSize \[bytes/lane\]|VGPRs):\s+(\d+)", line)
+        if m and cur:
+            kernels[cur][m.group(1)] = int(m.group(2))
+    assert len(kernels) > 40, "resource-usage remarks not found"
+    bad = {k: v for k, v in kernels.items() if v.get("VGPRs Spill", 0) or v.get("ScratchSize [bytes/lane]", 0)}
+    assert not bad, f"kernels that spill / use scratch: {bad}"
+    assert any("gemv_pair_kernel" in k for k in kernels) and any("residual_batch_mfma" in k for k in kernels)

@@ -165,6 +165,11 @@ int main(int argc, char** argv) {
       VX(512, 8, 1, 2, 2, false); VX(512, 8, 1, 2, 3, false); VX(512, 8, 1, 2, 2, true); VX(1024, 4, 1, 4, 2, true);
       VX(1024, 4, 1, 4, 3, false);
     }
+  } else if (bf16 && argc > 5) {
+#define VBX(T_, K_, R_, W_, NB_, IL_) vs.push_back({"bf16_t" #T_ "_k" #K_ "_r" #R_ "_nbuf" #NB_ "_il" #IL_, T_, K_, R_, 8, launch_variant<fos::bf16_t, T_, K_, R_, true, W_, NB_, IL_>})
+    VBX(1024, 2, 2, 4, 2, false); VBX(1024, 2, 1, 4, 3, false); VBX(1024, 2, 1, 4, 4, false); VBX(512, 4, 1, 2, 3, false);
+    VBX(512, 4, 2, 2, 2, false); VBX(1024, 2, 2, 4, 2, true); VBX(512, 4, 1, 2, 2, true); VBX(1024, 2, 1, 4, 2, true);
+    VBX(512, 4, 1, 2, 4, false);
   } else if (bf16) {
     if (n <= 8192) { VB(256, 4, 2, true, 2); VB(512, 2, 2, true, 2); VB(512, 2, 4, true, 2); VB(1024, 1, 4, true, 4); VB(1024, 1, 2, true, 4); }
     else { VB(512, 4, 2, true, 2); VB(512, 4, 1, true, 2); VB(512, 4, 1, true, 4); VB(1024, 2, 2, true, 4); VB(1024, 2, 1, true, 4); VB(1024, 2, 4, true, 4); VB(512, 4, 2, false, 2); }
