@@ -23,9 +23,15 @@ namespace fos {
 
 constexpr int BT_NV = 16;            // candidates per pass (MFMA N)
 constexpr int BT_ROWS = 64;          // rows per tile  (4 waves x 16)
-constexpr int BT_COLS = 64;          // columns per tile
+#ifndef FOS_BT_COLS
+#define FOS_BT_COLS 64
+#endif
+constexpr int BT_COLS = FOS_BT_COLS; // columns per tile (row segments of 4*BT_COLS bytes per load instruction group)
 constexpr int BT_LDS_STRIDE = BT_COLS + 4;   // padded row stride (floats): rows land on distinct bank groups
 constexpr int BT_THREADS = 256;
+constexpr int BT_F4_ROW = BT_COLS / 4;                               // float4 per tile row
+constexpr int BT_A_LOADS = BT_ROWS * BT_F4_ROW / BT_THREADS;         // float4 of A per thread per tile
+constexpr int BT_X_LOADS = BT_COLS * BT_NV / 4 / BT_THREADS;         // float4 of the candidate block per thread per tile
 constexpr int BT_W = 3 * BT_NV + 2;  // per-workgroup outputs of the candidate kernel
 
 // X block layout ("Xp"): for column k and candidate j,
@@ -35,6 +41,8 @@ constexpr int BT_W = 3 * BT_NV + 2;  // per-workgroup outputs of the candidate k
 __device__ __host__ inline int64_t xp_index(int64_t k, int j) {
   return ((k / 16) * 4 + (k % 16) / 4) * 64 + (int64_t)j * 4 + (k % 4);
 }
+
+static_assert(BT_COLS % 16 == 0 && BT_A_LOADS >= 1 && BT_X_LOADS >= 1, "tile shape");
 
 // Candidate generation: dlt_j (fp64 -> fp32, written in Xp layout) and per-candidate sums.
 // part[wg] = { gd_j (16), dd_j (16), nnz_j (16), ||grad||^2, ||y||^2 }.
@@ -113,53 +121,53 @@ __global__ __launch_bounds__(BT_THREADS, 2) void residual_batch_mfma_kernel(cons
   const int ktiles = (n + BT_COLS - 1) / BT_COLS;
   const int64_t ntiles = (g_hi > g_lo ? (g_hi - g_lo) : 0) * ktiles;
 
-  f32x4 areg[4];
-  f32x4 xreg;
-  auto load_tile = [&](int64_t t) {
+  // Two register sets: the loads of tile t+2 are issued while tile t is on the matrix cores and tile t+1 waits in
+  // registers for its turn in LDS -> two 16 KiB tiles in flight per workgroup (x 3 workgroups per CU).
+  f32x4 areg[2][BT_A_LOADS];
+  f32x4 xreg[2][BT_X_LOADS];
+  auto load_tile = [&](int set, int64_t t) {
     const int64_t grp = g_lo + t / ktiles;
     const int kt = (int)(t % ktiles);
     const int64_t row0 = grp * BT_ROWS;
     const int col0 = kt * BT_COLS;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < BT_A_LOADS; ++u) {
       const int f = u * BT_THREADS + tid;
-      int64_t row = row0 + f / 16;
-      int col = col0 + 4 * (f % 16);
+      int64_t row = row0 + f / BT_F4_ROW;
+      int col = col0 + 4 * (f % BT_F4_ROW);
       if (row >= m) row = m - 1;                 // clamped rows are masked when the residual is formed
       if (col >= n) col = n - 4;                 // clamped columns meet zero rows of Xp
-      areg[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A + row * lda + col));
+      areg[set][u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A + row * lda + col));
     }
-    xreg = *reinterpret_cast<const f32x4*>(xp + (int64_t)kt * (BT_COLS * BT_NV) + 4 * tid);
-  };
-  auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int f = u * BT_THREADS + tid;
-      *reinterpret_cast<f32x4*>(&a_s[buf][f / 16][4 * (f % 16)]) = areg[u];
-    }
-    *reinterpret_cast<f32x4*>(&x_s[buf][4 * tid]) = xreg;
+    for (int u = 0; u < BT_X_LOADS; ++u)
+      xreg[set][u] = *reinterpret_cast<const f32x4*>(xp + (int64_t)kt * (BT_COLS * BT_NV) + 4 * (u * BT_THREADS + tid));
   };
-
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  double qsum = 0.0;                              // this lane's candidate j = lane & 15, its 4 rows
-  if (ntiles > 0) {
-    load_tile(0);
-    store_tile(0);
-  }
-  __syncthreads();
-  for (int64_t t = 0; t < ntiles; ++t) {
-    const int buf = (int)(t & 1);
-    if (t + 1 < ntiles) load_tile(t + 1);         // global loads in flight behind the MFMAs
+  auto store_tile = [&](int set, int buf) {
+#pragma unroll
+    for (int u = 0; u < BT_A_LOADS; ++u) {
+      const int f = u * BT_THREADS + tid;
+      *reinterpret_cast<f32x4*>(&a_s[buf][f / BT_F4_ROW][4 * (f % BT_F4_ROW)]) = areg[set][u];
+    }
+#pragma unroll
+    for (int u = 0; u < BT_X_LOADS; ++u) *reinterpret_cast<f32x4*>(&x_s[buf][4 * (u * BT_THREADS + tid)]) = xreg[set][u];
+  };
+  // two accumulators (even / odd MFMA steps): v_mfma_f32_16x16x4_f32 issues every 32 cycles but a dependent one
+  // needs 40 - one chain would leave the pipe idle a fifth of the time (profiles: 27 % issue stall with one chain)
+  f32x4 acc_odd = {0.f, 0.f, 0.f, 0.f};
+  auto compute_tile = [&](int buf, int64_t t, f32x4& acc, double& qsum) {
 #pragma unroll
     for (int sub = 0; sub < BT_COLS / 16; ++sub) {
       const f32x4 a4 = *reinterpret_cast<const f32x4*>(&a_s[buf][16 * wave + (lane & 15)][16 * sub + 4 * (lane >> 4)]);
       const f32x4 x4 = *reinterpret_cast<const f32x4*>(&x_s[buf][(sub * 4 + (lane >> 4)) * 64 + (lane & 15) * 4]);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, x4.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, x4.y, acc, 0, 0, 0);
+      acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, x4.y, acc_odd, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, x4.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, x4.w, acc, 0, 0, 0);
+      acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, x4.w, acc_odd, 0, 0, 0);
     }
     if ((t + 1) % ktiles == 0) {
+      acc += acc_odd;
+      acc_odd = f32x4{0.f, 0.f, 0.f, 0.f};
       // row group complete: D[row = 4*(lane>>4)+reg][candidate = lane&15]
       const int64_t row0 = (g_lo + t / ktiles) * BT_ROWS + 16 * wave + 4 * (lane >> 4);
 #pragma unroll
@@ -173,7 +181,27 @@ __global__ __launch_bounds__(BT_THREADS, 2) void residual_batch_mfma_kernel(cons
       }
       acc = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (t + 1 < ntiles) store_tile(buf ^ 1);
+  };
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  double qsum = 0.0;                              // this lane's candidate j = lane & 15, its 4 rows
+  if (ntiles > 0) {
+    load_tile(0, 0);
+    store_tile(0, 0);
+  }
+  if (ntiles > 1) load_tile(1, 1);                // tile 1 waits in register set 1
+  __syncthreads();
+  for (int64_t t = 0; t < ntiles; t += 2) {
+    // even step: tile t in LDS buffer 0, tile t+1 in register set 1
+    if (t + 2 < ntiles) load_tile(0, t + 2);
+    compute_tile(0, t, acc, qsum);
+    if (t + 1 < ntiles) store_tile(1, 1);
+    __syncthreads();
+    if (t + 1 >= ntiles) break;
+    // odd step: tile t+1 in LDS buffer 1, tile t+2 in register set 0
+    if (t + 3 < ntiles) load_tile(1, t + 3);
+    compute_tile(1, t + 1, acc, qsum);
+    if (t + 2 < ntiles) store_tile(0, 0);
     __syncthreads();
   }
   // lanes j, j+16, j+32, j+48 hold candidate j
