@@ -41,10 +41,10 @@ using fos::YSource;
 typedef void (*FusedLaunch)(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw,
                             float* slabs, double* rr_part, double* rr2_part, int nwg, hipStream_t st);
 
-template <typename T, int THREADS, int K, int R, int MINW, bool WITH_G, int NBUF, bool DUAL>
+template <typename T, int THREADS, int K, int R, int MINW, bool WITH_G, int NBUF, bool DUAL, bool DRAIN = false>
 void fused_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, float* slabs,
                   double* rr_part, double* rr2_part, int nwg, hipStream_t st) {
-  hipLaunchKernelGGL((fos::gemv_pair_kernel<T, THREADS, K, R, true, MINW, WITH_G, NBUF, false, DUAL>), dim3(nwg),
+  hipLaunchKernelGGL((fos::gemv_pair_kernel<T, THREADS, K, R, true, MINW, WITH_G, NBUF, false, DUAL, DRAIN>), dim3(nwg),
                      dim3(THREADS), 0, st, reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part,
                      rr2_part);
 }
@@ -59,17 +59,22 @@ struct MenuEntry {
 #define ENTRY_NB(DT, T, TH, K, R, W, NB) \
   { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, NB, false>, fused_launch<T, TH, K, R, W, false, NB, false>, \
     fused_launch<T, TH, K, R, W, true, 2, true> }
+// drained pipeline (profiles/r01_kbench_exp2_*: best form for 64 KiB rows), with DUAL
+// The DUAL pass of such an entry runs another geometry of the same row step R (the 1024-thread form has no registers
+// left for the second vector): TH2 x K2 must cover the same n.
+#define ENTRY_DRAIN(DT, T, TH, K, R, W, TH2, K2, W2) \
+  { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, 2, false, true>, fused_launch<T, TH, K, R, W, false, 2, false, true>, \
+    fused_launch<T, TH2, K2, R, W2, true, 2, true, false> }
 #define ENTRY_D(DT, T, TH, K, R, W) \
   { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, 2, false>, fused_launch<T, TH, K, R, W, false, 2, false>, \
     fused_launch<T, TH, K, R, W, true, 2, true> }
 // Ordered by capacity (threads*k*EPC columns); first entry that fits n is the default.
 const MenuEntry kMenu[] = {
     ENTRY_D(FOS_F32, float, 256, 1, 4, 2), ENTRY_D(FOS_F32, float, 256, 2, 4, 2), ENTRY_D(FOS_F32, float, 256, 4, 2, 2),
-    ENTRY_NB(FOS_F32, float, 512, 4, 2, 2, 3),   ENTRY_D(FOS_F32, float, 512, 8, 1, 2),  ENTRY(FOS_F32, float, 512, 8, 2, 2),
-    ENTRY(FOS_F32, float, 1024, 4, 1, 4),  ENTRY(FOS_F32, float, 1024, 2, 2, 4),
+    ENTRY_NB(FOS_F32, float, 512, 4, 1, 2, 3),   ENTRY_DRAIN(FOS_F32, float, 1024, 4, 1, 4, 512, 8, 2),
+    ENTRY_D(FOS_F32, float, 512, 8, 1, 2),  ENTRY(FOS_F32, float, 1024, 2, 2, 4),
     ENTRY(FOS_BF16, fos::bf16_t, 256, 1, 4, 2), ENTRY(FOS_BF16, fos::bf16_t, 256, 2, 2, 2),
-    ENTRY(FOS_BF16, fos::bf16_t, 256, 4, 2, 2), ENTRY_NB(FOS_BF16, fos::bf16_t, 512, 4, 1, 2, 4),
-    ENTRY(FOS_BF16, fos::bf16_t, 512, 4, 2, 2),
+    ENTRY_NB(FOS_BF16, fos::bf16_t, 256, 4, 1, 2, 3), ENTRY_NB(FOS_BF16, fos::bf16_t, 512, 4, 1, 2, 3),
 };
 
 const MenuEntry* find_entry(int dtype, int threads, int k, int r) {

@@ -73,7 +73,7 @@ def test_gemv_pair_paths_and_layouts(fos):
         assert _data.rel(g, g_ref) < TOL, name
 
 
-@pytest.mark.parametrize("threads,chunks,rows", [(256, 4, 2), (512, 4, 2), (512, 8, 2), (512, 8, 1), (1024, 4, 1), (1024, 2, 2)])
+@pytest.mark.parametrize("threads,chunks,rows", [(256, 4, 2), (512, 4, 1), (512, 8, 1), (1024, 4, 1), (1024, 2, 2)])
 def test_every_fused_geometry(fos, threads, chunks, rows):
     rng = np.random.default_rng(threads + chunks)
     m = 1237
@@ -521,3 +521,24 @@ def test_ista_from_nonzero_start(fos):
     # CPU tensors in -> CPU tensors out
     xt = fos.ista(torch.from_numpy(x0), ls, ls.grad, fos.L1Prox(a1), L, max_iter=30)
     assert isinstance(xt, torch.Tensor) and not xt.is_cuda and _data.rel(xt.numpy(), x_ref) < TOL
+
+
+def test_history_on_wide_rows_uses_sibling_dual_kernel(fos):
+    """n in (8192, 16384]: the gradient runs the drained 1024-thread geometry, the DUAL (history) pass a 512-thread
+    sibling of the same row step; iterates and objectives must match the oracle either way."""
+    rng = np.random.default_rng(8)
+    m, n = 600, 16384
+    A = rng.standard_normal((m, n)).astype(np.float32)
+    b = rng.standard_normal(m).astype(np.float32)
+    A64, b64 = A.astype(np.float64), b.astype(np.float64)
+    lam = float(np.max(np.abs(A64.T @ b64)))
+    L = float(np.linalg.norm(A64, 2) ** 2)
+    prob = fos.prepare(A, b)
+    assert prob.plan()["threads"] == 1024 and prob.plan()["path"] == 0
+    x, h = fos.fista(prob, None, "elasticnet", 0.2 * lam, 0.5, max_iter=12, L=L, return_history=True)
+    x_ref, h_ref = orc.fista(A64, b64, "elasticnet", 0.2 * lam, 0.5, max_iter=12, L=L, return_history=True)
+    assert len(h["obj"]) == 12 and len(h["x"]) == 13
+    assert np.allclose(h["obj"], h_ref["obj"], rtol=TOL)
+    assert _data.rel(x, x_ref) < TOL
+    x2 = fos.fista(prob, None, "elasticnet", 0.2 * lam, 0.5, max_iter=12, L=L)
+    assert _data.rel(x2, x_ref) < TOL

@@ -55,10 +55,10 @@ struct Variant {
   void (*launch)(const void*, int64_t, const float*, int64_t, int, fos::YSource, int64_t, float*, double*, int, hipStream_t);
 };
 
-template <typename T, int THREADS, int K, int R, bool NT, int MINW, int NBUF = 2, bool IL = false>
+template <typename T, int THREADS, int K, int R, bool NT, int MINW, int NBUF = 2, bool IL = false, bool DRAIN = false>
 void launch_variant(const void* A, int64_t lda, const float* b, int64_t m, int n, fos::YSource ys, int64_t rpw,
                     float* slabs, double* rr, int nwg, hipStream_t st) {
-  hipLaunchKernelGGL((fos::gemv_pair_kernel<T, THREADS, K, R, NT, MINW, true, NBUF, IL>), dim3(nwg), dim3(THREADS), 0, st,
+  hipLaunchKernelGGL((fos::gemv_pair_kernel<T, THREADS, K, R, NT, MINW, true, NBUF, IL, false, DRAIN>), dim3(nwg), dim3(THREADS), 0, st,
                      (const T*)A, lda, b, m, n, ys, rpw, slabs, rr, (double*)nullptr);
 }
 
@@ -156,20 +156,20 @@ int main(int argc, char** argv) {
 #define VB(T_, K_, R_, NT_, W_) vs.push_back({"bf16_t" #T_ "_k" #K_ "_r" #R_ "_nt" #NT_ "_w" #W_, T_, K_, R_, 8, launch_variant<fos::bf16_t, T_, K_, R_, NT_, W_>})
 #define VX(T_, K_, R_, W_, NB_, IL_) vs.push_back({"t" #T_ "_k" #K_ "_r" #R_ "_nbuf" #NB_ "_il" #IL_, T_, K_, R_, 4, launch_variant<float, T_, K_, R_, true, W_, NB_, IL_>})
   if (!bf16 && argc > 5) {
-    // experiment set: deeper prefetch / interleaved rows
+    // experiment set: pipeline depth / rows per step (after the counted-vmcnt restructure)
     if (n <= 8192) {
-      VX(512, 4, 2, 2, 2, false); VX(512, 4, 2, 2, 3, false); VX(512, 4, 2, 2, 4, false); VX(512, 4, 1, 2, 4, false);
-      VX(512, 4, 2, 2, 2, true); VX(512, 4, 2, 2, 3, true); VX(512, 4, 1, 2, 3, true); VX(1024, 2, 2, 4, 3, false);
-      VX(1024, 2, 2, 4, 2, true); VX(256, 8, 1, 2, 3, false); VX(512, 4, 1, 2, 2, true);
+      VX(512, 4, 2, 2, 2, false); VX(512, 4, 2, 2, 3, false); VX(512, 4, 1, 2, 3, false); VX(512, 4, 1, 2, 4, false);
+      VX(512, 4, 1, 2, 2, false); VX(1024, 2, 2, 4, 2, false); VX(1024, 2, 1, 4, 3, false); VX(256, 8, 1, 2, 2, false);
+      VX(512, 4, 4, 2, 2, false); VX(1024, 2, 1, 4, 4, false);
     } else {
-      VX(512, 8, 1, 2, 2, false); VX(512, 8, 1, 2, 3, false); VX(512, 8, 1, 2, 2, true); VX(1024, 4, 1, 4, 2, true);
-      VX(1024, 4, 1, 4, 3, false);
+#define VXD(T_, K_, R_, W_, NB_, IL_) vs.push_back({"t" #T_ "_k" #K_ "_r" #R_ "_nbuf" #NB_ "_il" #IL_ "_DRAIN", T_, K_, R_, 4, launch_variant<float, T_, K_, R_, true, W_, NB_, IL_, true>})
+      VX(512, 8, 1, 2, 2, false); VXD(512, 8, 1, 2, 2, false); VX(1024, 4, 1, 4, 2, false); VXD(1024, 4, 1, 4, 2, false);
+      VX(512, 8, 1, 2, 2, true); VXD(512, 8, 1, 2, 2, true);
     }
   } else if (bf16 && argc > 5) {
 #define VBX(T_, K_, R_, W_, NB_, IL_) vs.push_back({"bf16_t" #T_ "_k" #K_ "_r" #R_ "_nbuf" #NB_ "_il" #IL_, T_, K_, R_, 8, launch_variant<fos::bf16_t, T_, K_, R_, true, W_, NB_, IL_>})
-    VBX(1024, 2, 2, 4, 2, false); VBX(1024, 2, 1, 4, 3, false); VBX(1024, 2, 1, 4, 4, false); VBX(512, 4, 1, 2, 3, false);
-    VBX(512, 4, 2, 2, 2, false); VBX(1024, 2, 2, 4, 2, true); VBX(512, 4, 1, 2, 2, true); VBX(1024, 2, 1, 4, 2, true);
-    VBX(512, 4, 1, 2, 4, false);
+    VBX(512, 4, 1, 2, 2, false); VBX(512, 4, 1, 2, 3, false); VBX(1024, 2, 1, 4, 2, false); VBX(1024, 2, 1, 4, 3, false);
+    VBX(256, 4, 1, 2, 3, false);
   } else if (bf16) {
     if (n <= 8192) { VB(256, 4, 2, true, 2); VB(512, 2, 2, true, 2); VB(512, 2, 4, true, 2); VB(1024, 1, 4, true, 4); VB(1024, 1, 2, true, 4); }
     else { VB(512, 4, 2, true, 2); VB(512, 4, 1, true, 2); VB(512, 4, 1, true, 4); VB(1024, 2, 2, true, 4); VB(1024, 2, 1, true, 4); VB(1024, 2, 4, true, 4); VB(512, 4, 2, false, 2); }
