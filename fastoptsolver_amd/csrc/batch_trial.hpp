@@ -185,24 +185,30 @@ __global__ __launch_bounds__(BT_THREADS, 2) void residual_batch_mfma_kernel(cons
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   double qsum = 0.0;                              // this lane's candidate j = lane & 15, its 4 rows
+  // Straight-line pair loop: loads and LDS stores are unconditional (tile index clamped to the last tile: redundant
+  // L2 hits at the tail), so the compiler can wait for a register set with a COUNTED vmcnt and leave the set it has
+  // just issued in flight.  A conditional load_tile / store_tile forces vmcnt(0) (DESIGN.md "What the ISA showed").
   if (ntiles > 0) {
+    const int64_t last = ntiles - 1;
+    auto clampt = [&](int64_t t) { return t < last ? t : last; };
     load_tile(0, 0);
     store_tile(0, 0);
-  }
-  if (ntiles > 1) load_tile(1, 1);                // tile 1 waits in register set 1
-  __syncthreads();
-  for (int64_t t = 0; t < ntiles; t += 2) {
-    // even step: tile t in LDS buffer 0, tile t+1 in register set 1
-    if (t + 2 < ntiles) load_tile(0, t + 2);
-    compute_tile(0, t, acc, qsum);
-    if (t + 1 < ntiles) store_tile(1, 1);
+    load_tile(1, clampt(1));                      // tile 1 waits in register set 1
     __syncthreads();
-    if (t + 1 >= ntiles) break;
-    // odd step: tile t+1 in LDS buffer 1, tile t+2 in register set 0
-    if (t + 3 < ntiles) load_tile(1, t + 3);
-    compute_tile(1, t + 1, acc, qsum);
-    if (t + 2 < ntiles) store_tile(0, 0);
-    __syncthreads();
+    int64_t t = 0;
+    for (; t + 2 <= ntiles; t += 2) {
+      // even step: tile t in LDS buffer 0, tile t+1 in register set 1
+      load_tile(0, clampt(t + 2));
+      compute_tile(0, t, acc, qsum);
+      store_tile(1, 1);
+      __syncthreads();
+      // odd step: tile t+1 in LDS buffer 1, tile t+2 in register set 0
+      load_tile(1, clampt(t + 3));
+      compute_tile(1, t + 1, acc, qsum);
+      store_tile(0, 0);
+      __syncthreads();
+    }
+    if (t < ntiles) compute_tile(0, t, acc, qsum);   // odd count: the last tile sits in buffer 0
   }
   // lanes j, j+16, j+32, j+48 hold candidate j
   qsum += __shfl_xor(qsum, 16, 64);
