@@ -15,10 +15,9 @@ engine below drives the HIP kernels and has no CPU fallback.
 """
 import math
 
-import torch
 import torch.distributed as dist
 
-from . import _core, _lib
+from . import _core
 
 
 def shard_rows(m, world, rank):
@@ -109,13 +108,3 @@ def sharded_lipschitz(matvec, n, v0, n_iter=100, tol=1e-6, group=None, ops=HipVe
             break
         prev = L
     return L
-
-
-def make_hip_matvec(A_shard):
-    """w_partial = A_p^T (A_p v) through the single-pass kernel with b = 0."""
-    prob = _core.Problem(A_shard, None)
-
-    def matvec(v):
-        return prob.gemv_pair(v, 0.0)
-    matvec.prob = prob
-    return matvec

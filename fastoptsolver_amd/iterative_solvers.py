@@ -94,6 +94,7 @@ def estimate_lipschitz(A, n_iter: int = 100, tol: float = 1e-6) -> float:
 # Armijo acceptance (ref:191, :306, :101) in cancellation-free form
 # ---------------------------------------------------------------------
 _BATCH = 16      # candidate steps decided per pass over A (MFMA N dimension)
+_HISTORY_CHUNK_BYTES = 256 << 20   # device-resident x history is read back in chunks of at most this size
 
 
 def _armijo_accepts(tr, t_k, smooth_a2):
@@ -153,20 +154,28 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
     # by the same two kernels of the plain run and read back once (ref:224-232, :319-322).
     plain = not (mode == _lib.MODE_FISTA and adaptive_restart) and tol == 0.0 and tol_ratio == 0.0
     if history is not None and log is None and not backtracking and plain and max_iter > 0:
-        ev = gtimer.start()
-        rec = st.run_history(max_iter)
-        if rec is not None:
-            gtimer.stop(ev, max_iter)
+        chunk = max(1, min(max_iter, _HISTORY_CHUNK_BYTES // (8 * prob.n)))     # bound the device-side x history
+        done, supported = 0, True
+        while done < max_iter and supported:
+            todo = min(chunk, max_iter - done)
+            ev = gtimer.start()
+            rec = st.run_history(todo)
+            if rec is None:
+                supported = False
+                gtimer.pending.clear()
+                break
+            gtimer.stop(ev, todo)
             xh, hs = rec
             hs = hs.cpu().numpy()
             if like.tensor:
-                history["x"].extend(_core.from_device_vec(xh[i], like) for i in range(max_iter))
+                history["x"].extend(_core.from_device_vec(xh[i], like) for i in range(todo))
             else:
                 history["x"].extend(list(xh.cpu().numpy()))
             history["obj"].extend(history_obj(float(r[0]), float(r[2]), float(r[1])) for r in hs)
+            done += todo
+        if supported:
             gtimer.flush()
             return st
-        gtimer.pending.clear()
 
     # History objective f(x_k) without the reference's extra pass per iteration (ref:225-230, :321): the DUAL
     # gradient pass of iteration k also returns ||A x_k - b||^2, so f(x_k) is appended one iteration late and only

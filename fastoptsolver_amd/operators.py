@@ -1,7 +1,5 @@
 """Device callables for ``ista`` (the reference passes closures; these are the recognised, fusable
 equivalents) and thin wrappers over the vector kernels."""
-import ctypes as C
-
 import torch
 
 from . import _core, _lib

@@ -1,8 +1,6 @@
 """GPU parity tests: the HIP path (through the C ABI) vs the oracle and vs the golden vectors captured from
 the reference.  Tolerance: 1e-5 relative on iterates (BASELINE.json north_star: "iterates match the NumPy
 reference to 1e-5 relative fp32"); counts (gradient calls, line-search shrinks, iterations) must be equal."""
-import math
-
 import numpy as np
 import pytest
 import torch
@@ -542,3 +540,18 @@ def test_history_on_wide_rows_uses_sibling_dual_kernel(fos):
     assert _data.rel(x, x_ref) < TOL
     x2 = fos.fista(prob, None, "elasticnet", 0.2 * lam, 0.5, max_iter=12, L=L)
     assert _data.rel(x2, x_ref) < TOL
+
+
+def test_history_chunking_is_transparent(fos, monkeypatch):
+    """The device-resident history is read back in bounded chunks; the result must not depend on the chunk size."""
+    from fastoptsolver_amd import iterative_solvers as its
+    A, b, fx = _data.problem("aligned")
+    prob = fos.prepare(A, b)
+    lam = float(np.max(np.abs(A.T @ b)))
+    L = float(fx["aligned/L"])
+    x1, h1 = fos.fista(prob, None, "lasso", 0.1 * lam, 0.0, max_iter=37, L=L, return_history=True)
+    monkeypatch.setattr(its, "_HISTORY_CHUNK_BYTES", 8 * A.shape[1] * 5)        # 5 iterations per chunk
+    x2, h2 = fos.fista(prob, None, "lasso", 0.1 * lam, 0.0, max_iter=37, L=L, return_history=True)
+    assert len(h2["x"]) == 38 and len(h2["obj"]) == 37
+    assert np.array_equal(x1, x2) and all(np.array_equal(a, c) for a, c in zip(h1["x"], h2["x"]))
+    assert np.allclose(h1["obj"], h2["obj"], rtol=1e-12)

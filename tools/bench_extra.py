@@ -4,7 +4,6 @@
   cfg5' bf16 A / fp32 accumulate elastic-net step at 131072 x 16384 (one 8-GPU shard of cfg5)
   pcie  fista() end to end when the boundary is handed HOST ndarrays (upload + power iteration + 500 iterations)
 """
-import ctypes as C
 import json
 import os
 import sys
