@@ -65,12 +65,18 @@ class Problem:
     Build it once with ``prepare(A, b)`` and pass it wherever the solvers take ``A`` to avoid re-uploading A.
     """
 
-    def __init__(self, A, b=None, dtype=None):
+    def __init__(self, A, b=None, dtype=None, pad=None):
+        """pad: zero-pad the columns of the device copy of A to the fused kernel's granularity (4 fp32 / 8 bf16
+        elements, 16-byte aligned rows) so that a ragged n or a misaligned view still gets the single-pass kernel
+        (4x faster than the two-pass path at 65536 x 8190).  Zero columns stay exactly zero through gradient and
+        prox, and every vector is padded / trimmed here, so callers never see them.  None = only for problems large
+        enough for it to matter (m*n >= 2^24); small ragged problems keep the fp64-accumulating two-pass path."""
         require_gpu()
         lib = _lib.load()
         self.like = Like(A)
         want_bf16 = (dtype in ("bf16", torch.bfloat16)) or (dtype is None and is_tensor(A) and A.dtype == torch.bfloat16)
         tdtype = torch.bfloat16 if want_bf16 else torch.float32
+        gran = 8 if want_bf16 else 4
         dev = A.device if is_tensor(A) and A.is_cuda else torch.device("cuda", torch.cuda.current_device())
         if is_tensor(A):
             At = A.detach()
@@ -78,21 +84,33 @@ class Problem:
             At = torch.from_numpy(np.asarray(A))
         if At.dim() != 2:
             raise ValueError("A must be 2-D")
-        if not (At.is_cuda and At.dtype == tdtype and At.stride(1) == 1 and At.stride(0) >= At.shape[1]):
+        m, n = int(At.shape[0]), int(At.shape[1])
+        borrowable = At.is_cuda and At.dtype == tdtype and At.stride(1) == 1 and At.stride(0) >= n
+        esz = 2 if want_bf16 else 4
+        fused_ok = borrowable and n % gran == 0 and (At.stride(0) % gran == 0 or m == 1) and At.data_ptr() % 16 == 0
+        if pad is None:
+            pad = (not fused_ok) and m * n >= (1 << 24)
+        n_dev = n
+        if pad and not fused_ok:
+            n_dev = (n + gran - 1) // gran * gran
+            Ap = torch.zeros(m, n_dev, dtype=tdtype, device=dev)
+            Ap[:, :n].copy_(At)                      # one strided copy (host->device or device->device)
+            At = Ap
+        elif not borrowable:
             At = At.to(device=dev, dtype=tdtype).contiguous()
         self.A = At
-        self.m, self.n = int(At.shape[0]), int(At.shape[1])
-        self.lda = int(At.stride(0)) if self.m > 1 else self.n
+        self.m, self.n, self.n_dev = m, n, n_dev
+        self.lda = int(At.stride(0)) if self.m > 1 else self.n_dev
         self.device = At.device
         self.dtype = "bf16" if want_bf16 else "f32"
         self.b = None if b is None else to_device_vec(b, self.device)
         if self.b is not None and self.b.numel() != self.m:
             raise ValueError("b must have m entries")
-        self.gbuf = torch.zeros(self.n + 4, dtype=torch.float32, device=self.device)
+        self.gbuf = torch.zeros(self.n_dev + 4, dtype=torch.float32, device=self.device)
         self.scratch = torch.zeros(32, dtype=torch.float64, device=self.device)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(lib.fos_problem_create(C.byref(h), ptr(self.A), self.m, self.n, self.lda,
+            _lib.check(lib.fos_problem_create(C.byref(h), ptr(self.A), self.m, self.n_dev, self.lda,
                                               _lib.FOS_BF16 if want_bf16 else _lib.FOS_F32, ptr(self.b), stream_ptr()),
                        "fos_problem_create")
             self.h = h
@@ -107,6 +125,23 @@ class Problem:
             except Exception:
                 pass
             self.h = None
+
+    # ---- user-length <-> device-length vectors ------------------------------------------------------------
+    def vec_in(self, x, dtype=torch.float32):
+        """1-D device tensor of the kernel's length n_dev (zero beyond n) from a user vector of length n or n_dev."""
+        t = x.detach() if is_tensor(x) else torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+        t = t.to(device=self.device, dtype=dtype).contiguous()
+        if t.numel() == self.n_dev:
+            return t
+        if t.numel() != self.n:
+            raise ValueError(f"expected a vector of length {self.n}")
+        out = torch.zeros(self.n_dev, dtype=dtype, device=self.device)
+        out[: self.n] = t
+        return out
+
+    def vec_out(self, t):
+        """Trim a device-length vector (or [k, n_dev] history block) to the user's n."""
+        return t if self.n_dev == self.n else t[..., : self.n]
 
     # ---- plan / tuning -------------------------------------------------------------------------------
     def plan(self):
@@ -132,16 +167,20 @@ class Problem:
     # ---- kernels -------------------------------------------------------------------------------------
     def gemv_pair(self, y, alpha2=0.0, out=None, rr_out=None):
         """grad = A^T (A y - b) + alpha2 y (device tensor); rr_out: optional 1-element float64 device tensor."""
-        if out is None:
-            out = torch.empty(self.n, dtype=torch.float32, device=self.device)
-        y = to_device_vec(y, self.device)
+        user_out = out
+        if out is None or out.numel() != self.n_dev:
+            out = torch.empty(self.n_dev, dtype=torch.float32, device=self.device)
+        y = self.vec_in(y)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.fos_gemv_pair(self.h, ptr(y), float(alpha2), ptr(out), ptr(rr_out)), "fos_gemv_pair")
-        return out
+        if user_out is not None and user_out is not out:
+            user_out.copy_(self.vec_out(out))
+            return user_out
+        return self.vec_out(out)
 
     def residual_objective(self, x):
         """Host tuple (||Ax-b||^2, ||x||^2, ||x||_1); synchronises.  x is rounded to fp32 for the pass over A."""
-        x = to_device_vec(x, self.device)
+        x = self.vec_in(x)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.fos_residual_objective(self.h, ptr(x), ptr(self.scratch)), "fos_residual_objective")
         v = self.scratch[:3].cpu()
@@ -151,26 +190,26 @@ class Problem:
         """||A X_j - b||^2 for the <= 16 columns of X (n x nv) in one MFMA pass; host list.  Synchronises."""
         X = torch.as_tensor(X, device=self.device, dtype=torch.float32)
         nv = X.shape[1]
-        Xf = torch.zeros(self.n, 16, dtype=torch.float32, device=self.device)
-        Xf[:, :nv] = X
+        Xf = torch.zeros(self.n_dev, 16, dtype=torch.float32, device=self.device)
+        Xf[: X.shape[0], :nv] = X
         with torch.cuda.device(self.device):
             _lib.check(self.lib.fos_residual_batch(self.h, ptr(Xf), nv, int(bool(use_b)), ptr(self.scratch)),
                        "fos_residual_batch")
         return self.scratch[:nv].cpu().tolist()
 
     def power_iter(self, v0, n_iter=100, tol=1e-6):
-        v = to_device_vec(v0, self.device).clone()
+        v = self.vec_in(v0).clone()
         L = C.c_double()
         it = C.c_int()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.fos_power_iter(self.h, ptr(v), int(n_iter), float(tol), C.byref(L), C.byref(it)),
                        "fos_power_iter")
-        return L.value, it.value, v
+        return L.value, it.value, self.vec_out(v)
 
 
-def prepare(A, b=None, dtype=None):
+def prepare(A, b=None, dtype=None, pad=None):
     """Upload/bind A (and b) once; the result can be passed as ``A`` to every solver (``b`` may then be None)."""
-    return A if isinstance(A, Problem) else Problem(A, b, dtype)
+    return A if isinstance(A, Problem) else Problem(A, b, dtype, pad)
 
 
 def as_problem(A, b, dtype=None):
@@ -208,6 +247,8 @@ class Fista:
         p.tau, p.alpha1, p.alpha2, p.delta = float(tau), float(alpha1), float(alpha2), float(delta)
         p.restart_threshold, p.tol_step, p.tol_ratio = float(restart_threshold), float(tol_step), float(tol_ratio)
         p.mode, p.prox_kind, p.adaptive_restart, p.reserved = int(mode), int(prox_kind), int(bool(adaptive_restart)), 0
+        if x0 is not None:
+            x0 = self.prob.vec_in(x0, torch.float64)
         with torch.cuda.device(self.prob.device):
             _lib.check(self.lib.fos_fista_reset(self.h, C.byref(p), ptr(x0)), "fos_fista_reset")
 
@@ -223,7 +264,7 @@ class Fista:
         {||Ax-b||^2, ||x||_1, ||x||_2^2, ||dx||^2}) as device tensors, or None when this solver configuration /
         problem shape needs the host-driven loop."""
         dev = self.prob.device
-        xh = torch.empty(iters, self.prob.n, dtype=torch.float64, device=dev)
+        xh = torch.empty(iters, self.prob.n_dev, dtype=torch.float64, device=dev)
         hist = torch.empty(iters, 4, dtype=torch.float64, device=dev)
         nbytes = self.lib.fos_fista_history_workspace(self.h, int(iters))
         work = torch.empty(max(1, (nbytes + 7) // 8), dtype=torch.float64, device=dev)
@@ -233,7 +274,7 @@ class Fista:
             return None
         _lib.check(rc, "fos_fista_run_history")
         self._keep = work            # stays alive until the stream has consumed it (next sync)
-        return xh, hist
+        return self.prob.vec_out(xh), hist
 
     def grad(self, dual=False):
         """Gradient pass at y_k; dual=True also leaves ||A x_k - b||^2 in status().rr_x (same pass over A)."""
@@ -274,7 +315,7 @@ class Fista:
 
     def x_tensor(self):
         """Copy of x_k as a float64 device tensor."""
-        out = torch.empty(self.prob.n, dtype=torch.float64, device=self.prob.device)
+        out = torch.empty(self.prob.n_dev, dtype=torch.float64, device=self.prob.device)
         with torch.cuda.device(self.prob.device):
             _lib.check(self.lib.fos_fista_get_x(self.h, ptr(out)), "fos_fista_get_x")
-        return out
+        return self.prob.vec_out(out)

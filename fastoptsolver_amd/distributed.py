@@ -32,7 +32,7 @@ class HipShardEngine:
 
     def __init__(self, A_shard, b_shard, dtype=None):
         self.prob = _core.Problem(A_shard, b_shard, dtype)
-        self.n = self.prob.n
+        self.n = self.prob.n_dev             # device length: gbuf[n_dev] carries the partial ||r||^2
         self.st = _core.Fista(self.prob)
         self.gbuf = self.prob.gbuf            # torch tensor (n + 4 floats) the kernels write / read
 

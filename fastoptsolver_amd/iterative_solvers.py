@@ -122,7 +122,7 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
     """Run the state machine.  Device-driven when nothing needs a per-iteration host decision,
     host-driven otherwise (grad-norm stop ref:179, backtracking ref:183-197, history ref:224-232)."""
     st = _core.Fista(prob)
-    x0_dev = None if x0 is None else _core.to_device_vec(x0, prob.device).double()
+    x0_dev = None if x0 is None else _core.to_device_vec(x0, prob.device).double()   # padded by Fista.reset
     st.reset(tau, alpha1, alpha2, mode=mode, prox_kind=prox_kind, delta=delta, adaptive_restart=adaptive_restart,
              restart_threshold=restart_threshold, tol_step=tol if tol > 0.0 else 0.0,
              tol_ratio=tol_ratio if tol_ratio > 0.0 else 0.0, x0=x0_dev)
@@ -154,7 +154,7 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
     # by the same two kernels of the plain run and read back once (ref:224-232, :319-322).
     plain = not (mode == _lib.MODE_FISTA and adaptive_restart) and tol == 0.0 and tol_ratio == 0.0
     if history is not None and log is None and not backtracking and plain and max_iter > 0:
-        chunk = max(1, min(max_iter, _HISTORY_CHUNK_BYTES // (8 * prob.n)))     # bound the device-side x history
+        chunk = max(1, min(max_iter, _HISTORY_CHUNK_BYTES // (8 * prob.n_dev)))     # bound the device-side x history
         done, supported = 0, True
         while done < max_iter and supported:
             todo = min(chunk, max_iter - done)

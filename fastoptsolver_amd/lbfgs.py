@@ -54,7 +54,7 @@ class LBFGSSolver:
         lib = _lib.load()
         prob = _core.as_problem(A, b)
         like = prob.like
-        n, dev = prob.n, prob.device
+        n, dev = prob.n_dev, prob.device          # device length (zero-padded columns stay exactly zero)
         a2 = float(self.alpha2) if self.reg_type in ("ridge", "elasticnet") else 0.0   # lbfgs.py:49-51
         gtimer = _EventTimer(grad_call_times)
         stats = torch.zeros(8, dtype=torch.float64, device=dev)
@@ -87,7 +87,7 @@ class LBFGSSolver:
             return d
 
         def callback(xk):                                                           # lbfgs.py:56-61
-            self.iterates_.append(_core.from_device_vec(xk, like))
+            self.iterates_.append(_core.from_device_vec(prob.vec_out(xk), like))
             self.history_.append(compute_objective(xk, prob, None, self.reg_type, self.alpha1, self.alpha2))
 
         def step_to(x_old, stp, d):
@@ -175,7 +175,7 @@ class LBFGSSolver:
                 vec_axpby(stp, d, 0.0, None, out=S[slot])
                 vec_axpby(1.0, g, -1.0, g_old, out=Y[slot])
         gtimer.flush()
-        self.x_ = _core.from_device_vec(x, like)                                      # lbfgs.py:71
+        self.x_ = _core.from_device_vec(prob.vec_out(x), like)                        # lbfgs.py:71
         self.final_obj_ = f                                                           # lbfgs.py:72
         self.nit_, self.task_ = nit, task
         return self

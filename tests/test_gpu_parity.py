@@ -555,3 +555,38 @@ def test_history_chunking_is_transparent(fos, monkeypatch):
     assert len(h2["x"]) == 38 and len(h2["obj"]) == 37
     assert np.array_equal(x1, x2) and all(np.array_equal(a, c) for a, c in zip(h1["x"], h2["x"]))
     assert np.allclose(h1["obj"], h2["obj"], rtol=1e-12)
+
+
+def test_large_ragged_n_is_padded_onto_the_fused_path(fos):
+    """m*n >= 2^24 with n % 4 != 0: prepare() zero-pads the columns of its device copy so the single-pass kernel
+    applies; padding must be invisible (lengths, values) in every entry point."""
+    rng = np.random.default_rng(17)
+    m, n = 4100, 4098
+    A = rng.standard_normal((m, n)).astype(np.float32)
+    b = rng.standard_normal(m).astype(np.float32)
+    A64, b64 = A.astype(np.float64), b.astype(np.float64)
+    prob = fos.prepare(A, b)
+    assert prob.plan()["path"] == 0 and prob.n == n and prob.n_dev == 4100
+    assert fos.prepare(A, b, pad=False).plan()["path"] == 1
+    y = rng.standard_normal(n).astype(np.float32)
+    g = prob.gemv_pair(_dev(y), alpha2=0.2)
+    assert g.shape == (n,)
+    g_ref, rr_ref = orc.gram_gradient(A64, y.astype(np.float64), b64, 0.2)
+    assert _data.rel(g.cpu().numpy(), g_ref) < TOL
+    assert prob.residual_objective(_dev(y))[0] == pytest.approx(rr_ref, rel=TOL)
+    lam = float(np.max(np.abs(A64.T @ b64)))
+    L = float(np.linalg.norm(A64, 2) ** 2)
+    x, h = fos.fista(prob, None, "elasticnet", 0.1 * lam, 0.5, max_iter=25, L=L, return_history=True)
+    x_ref, h_ref = orc.fista(A64, b64, "elasticnet", 0.1 * lam, 0.5, max_iter=25, L=L, return_history=True)
+    assert x.shape == (n,) and all(v.shape == (n,) for v in h["x"])
+    assert _data.rel(x, x_ref) < TOL and np.allclose(h["obj"], h_ref["obj"], rtol=TOL)
+    xb = fos.fista(prob, None, "lasso", 0.1 * lam, 0.0, max_iter=15, L=L, backtracking=True, t_init_factor=2.0)
+    xb_ref = orc.fista(A64, b64, "lasso", 0.1 * lam, 0.0, max_iter=15, L=L, backtracking=True, t_init_factor=2.0)
+    assert _data.rel(xb, xb_ref) < TOL
+    np.random.seed(3)
+    v0 = np.random.randn(n)
+    np.random.seed(3)
+    assert fos.estimate_lipschitz(prob) == pytest.approx(orc.estimate_lipschitz(A64, v0=v0), rel=TOL)
+    s = fos.LBFGSSolver("ridge", 0.0, 1.0, max_iter=8).fit(prob, None)
+    s_ref = orc.LBFGSSolver("ridge", 0.0, 1.0, max_iter=8).fit(A64, b64)
+    assert s.x_.shape == (n,) and _data.rel(s.x_, s_ref.x_) < 2e-5
