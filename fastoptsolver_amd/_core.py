@@ -319,3 +319,16 @@ class Fista:
         with torch.cuda.device(self.prob.device):
             _lib.check(self.lib.fos_fista_get_x(self.h, ptr(out)), "fos_fista_get_x")
         return self.prob.vec_out(out)
+
+
+def run_multi(handles, iters):
+    """Advance up to 4 Fista handles of one Problem in lockstep (one pass over A per iteration for all of them).
+    Returns False when this shape / configuration has no multi-vector kernel (callers then run them one by one)."""
+    lib = handles[0].lib
+    arr = (C.c_void_p * len(handles))(*[h.h for h in handles])
+    with torch.cuda.device(handles[0].prob.device):
+        rc = lib.fos_fista_run_multi(arr, len(handles), int(iters))
+    if rc == -4:
+        return False
+    _lib.check(rc, "fos_fista_run_multi")
+    return True

@@ -11,6 +11,7 @@
 
 #include "../../include/fos.h"
 #include "batch_trial.hpp"
+#include "gemv_multi.hpp"
 #include "gemv_pair.hpp"
 #include "lbfgs_kernels.hpp"
 #include "reduce_update.hpp"
@@ -317,6 +318,24 @@ int launch_residual_batch(fos_problem* p, int use_b, double* out16) {
   hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->q_part, (int)nwg, fos::BT_NV, out16);
   LAUNCH_CHECK();
   return FOS_OK;
+}
+
+// ---- multi-lambda lockstep run ----------------------------------------------------------------------------------
+typedef void (*MultiLaunch)(const float* A, int64_t lda, const float* b, int64_t m, int n, fos::MultiY ys, int64_t rpw,
+                            float* slabs, double* rr_part, int nwg, hipStream_t st);
+template <int THREADS, int K, int NVEC>
+void multi_launch(const float* A, int64_t lda, const float* b, int64_t m, int n, fos::MultiY ys, int64_t rpw,
+                         float* slabs, double* rr_part, int nwg, hipStream_t st) {
+  hipLaunchKernelGGL((fos::gemv_multi_kernel<float, THREADS, K, 2, NVEC, 2>), dim3(nwg), dim3(THREADS), 0, st, A, lda, b,
+                     m, n, ys, rpw, slabs, rr_part);
+}
+MultiLaunch find_multi(int64_t n, int nv) {
+  static const MultiLaunch small[3] = {multi_launch<256, 4, 2>, multi_launch<256, 4, 3>, multi_launch<256, 4, 4>};
+  static const MultiLaunch big[3] = {multi_launch<512, 4, 2>, multi_launch<512, 4, 3>, multi_launch<512, 4, 4>};
+  if (nv < 2 || nv > 4) return nullptr;
+  if (n <= 4096) return small[nv - 2];
+  if (n <= 8192) return big[nv - 2];
+  return nullptr;
 }
 
 bool batch_supported(const fos_problem* p) { return p->path == 0 && p->dtype == FOS_F32; }
@@ -644,16 +663,18 @@ static void host_momentum(const fos::FistaParams& prm, long long k, double* t, d
 }
 
 static void launch_update_from_slabs(fos_fista* f, double* part, int host_beta, double beta_val,
-                                     double* x_hist = nullptr, float* y_next = nullptr, double beta_next = 0.0) {
+                                     double* x_hist = nullptr, float* y_next = nullptr, double beta_next = 0.0,
+                                     const float* slabs = nullptr, int64_t slab_stride = 0) {
   fos_problem* p = f->p;
+  if (slabs == nullptr) slabs = p->slabs;
   if (p->vec4)
-    hipLaunchKernelGGL((fos::fista_update_kernel<true, true>), dim3(f->nupd), dim3(256), 0, p->stream, p->slabs,
+    hipLaunchKernelGGL((fos::fista_update_kernel<true, true>), dim3(f->nupd), dim3(256), 0, p->stream, slabs,
                        p->nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
-                       beta_val, x_hist, y_next, beta_next);
+                       beta_val, x_hist, y_next, beta_next, slab_stride);
   else
-    hipLaunchKernelGGL((fos::fista_update_kernel<true, false>), dim3(f->nupd), dim3(256), 0, p->stream, p->slabs,
+    hipLaunchKernelGGL((fos::fista_update_kernel<true, false>), dim3(f->nupd), dim3(256), 0, p->stream, slabs,
                        p->nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
-                       beta_val, x_hist, y_next, beta_next);
+                       beta_val, x_hist, y_next, beta_next, slab_stride);
 }
 
 // y source of a plain-run iteration: the fp32 vector the previous update kernel wrote, or (first iteration after a
@@ -798,6 +819,84 @@ int fos_fista_run(fos_fista* f, int iters) {
     launch_update_from_slabs(f, p->part, 0, 0.0);
     LAUNCH_CHECK();
     if ((rc = launch_finalize(f, n_rr))) return rc;
+  }
+  return FOS_OK;
+}
+
+int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters) {
+  if (!fs || nv < 1 || nv > 4 || iters < 0) return fail(FOS_ERR_ARG, "fos_fista_run_multi: bad argument");
+  for (int v = 0; v < nv; ++v)
+    if (!fs[v] || fs[v]->p != fs[0]->p) return fail(FOS_ERR_ARG, "fos_fista_run_multi: handles must share one problem");
+  if (nv == 1) return fos_fista_run(fs[0], iters);
+  fos_problem* p = fs[0]->p;
+  MultiLaunch fn = (p->path == 0 && p->dtype == FOS_F32) ? find_multi(p->n, nv) : nullptr;
+  for (int v = 0; v < nv && fn; ++v)
+    if (!plain_run(fs[v])) fn = nullptr;
+  if (!fn) return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_multi: no multi-vector kernel for this shape / configuration");
+  if (iters == 0) return FOS_OK;
+  // workspace: nv interleaved slab sets and rr partials per workgroup
+  const int nwg = p->nwg;
+  if (nwg * nv > p->slab_cap) {
+    if (p->slabs) (void)hipFree(p->slabs);
+    p->slabs = nullptr;
+    p->slab_cap = 0;
+    HIP_TRY(hipMalloc(&p->slabs, (size_t)nwg * nv * p->n * sizeof(float)));
+    p->slab_cap = nwg * nv;
+  }
+  if (nwg * nv > p->rr_cap) {
+    if (p->rr_part) (void)hipFree(p->rr_part);
+    if (p->rr2_part) (void)hipFree(p->rr2_part);
+    p->rr_part = p->rr2_part = nullptr;
+    p->rr_cap = 0;
+    HIP_TRY(hipMalloc(&p->rr_part, (size_t)nwg * nv * sizeof(double)));
+    HIP_TRY(hipMalloc(&p->rr2_part, (size_t)nwg * nv * sizeof(double)));
+    p->rr_cap = nwg * nv;
+  }
+  fos::MultiY ys{};
+  ys.stopped = nullptr;
+  for (int v = 0; v < nv; ++v) {
+    fos_fista* f = fs[v];
+    int rc = flush_pending(f);
+    if (rc) return rc;
+    bool stopped = false;
+    if ((rc = refresh_host_scalars(f, &stopped))) return rc;
+    if (stopped) return fail(FOS_ERR_STATE, "fos_fista_run_multi: a handle has already stopped");
+    if (!f->y_valid) {
+      hipLaunchKernelGGL(fos::form_y_kernel, dim3(grid_1d(p->n, 256, 256)), dim3(256), 0, p->stream, f->x_cur, f->x_prev,
+                         f->h_beta, f->ynext, p->n);
+      LAUNCH_CHECK();
+      f->y_valid = true;
+    }
+    ys.y[v] = f->ynext;
+  }
+  for (int v = nv; v < 4; ++v) ys.y[v] = ys.y[0];
+  const size_t psz = (size_t)fs[0]->nupd * 4;
+  for (int it = 0; it < iters; ++it) {
+    int rc = prof_mark(p, true);
+    if (rc) return rc;
+    fn((const float*)p->A, p->lda, p->b, p->m, (int)p->n, ys, p->rows_per_wg, p->slabs, p->rr_part, nwg, p->stream);
+    LAUNCH_CHECK();
+    if ((rc = prof_mark(p, false))) return rc;
+    for (int v = 0; v < nv; ++v) {
+      fos_fista* f = fs[v];
+      const double beta_k = f->h_beta;
+      host_momentum(f->prm, f->h_k, &f->h_t, &f->h_beta);
+      launch_update_from_slabs(f, f->part2 + (size_t)(f->h_k & 1) * psz, 1, beta_k, nullptr, f->ynext, f->h_beta,
+                               p->slabs + (size_t)v * p->n, (int64_t)nv * p->n);
+      LAUNCH_CHECK();
+      f->h_k += 1;
+      f->plain_count += 1;
+    }
+  }
+  for (int v = 0; v < nv; ++v) {
+    fos_fista* f = fs[v];
+    f->pending = false;
+    const long long last = f->h_k - 1;
+    const double* cur = f->part2 + (size_t)(last & 1) * psz;
+    const double* prev = f->plain_count >= 2 ? f->part2 + (size_t)((last - 1) & 1) * psz : nullptr;
+    hipLaunchKernelGGL(fos::fista_finalize_plain_kernel, dim3(1), dim3(64), 0, p->stream, cur, prev, f->nupd, p->rr_part, 0,
+                       f->scal, f->h_t, f->h_beta, f->h_k);
+    LAUNCH_CHECK();
   }
   return FOS_OK;
 }

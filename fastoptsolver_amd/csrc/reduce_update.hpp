@@ -92,7 +92,8 @@ constexpr int RG = 16;             // slab groups per workgroup
 constexpr int RCOLS = RQ * 4;
 
 __device__ inline f32x4 reduce_slab_block(const float* __restrict__ slabs, int nslabs, int n, int col0,
-                                          f32x4 (*lds)[RQ]) {
+                                          f32x4 (*lds)[RQ], int64_t stride = 0) {
+  if (stride == 0) stride = n;       // distance between consecutive slabs (multi-lambda runs interleave NVEC sets)
   const int q = threadIdx.x % RQ, grp = threadIdx.x / RQ;
   const int col = col0 + 4 * q;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -100,13 +101,13 @@ __device__ inline f32x4 reduce_slab_block(const float* __restrict__ slabs, int n
     const float* p = slabs + col;
     int s = grp;
     for (; s + 3 * RG < nslabs; s += 4 * RG) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(p + (int64_t)s * n);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(p + (int64_t)(s + RG) * n);
-      const f32x4 c = *reinterpret_cast<const f32x4*>(p + (int64_t)(s + 2 * RG) * n);
-      const f32x4 d = *reinterpret_cast<const f32x4*>(p + (int64_t)(s + 3 * RG) * n);
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p + (int64_t)s * stride);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(p + (int64_t)(s + RG) * stride);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(p + (int64_t)(s + 2 * RG) * stride);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(p + (int64_t)(s + 3 * RG) * stride);
       acc += a; acc += b; acc += c; acc += d;
     }
-    for (; s < nslabs; s += RG) acc += *reinterpret_cast<const f32x4*>(p + (int64_t)s * n);
+    for (; s < nslabs; s += RG) acc += *reinterpret_cast<const f32x4*>(p + (int64_t)s * stride);
   }
   lds[grp][q] = acc;
   __syncthreads();
@@ -169,7 +170,8 @@ __global__ __launch_bounds__(256) void fista_update_kernel(const float* __restri
                                                           const FistaScalars* __restrict__ scal, FistaParams prm,
                                                           double* __restrict__ part, int host_beta, double beta_val,
                                                           double* __restrict__ x_hist = nullptr,
-                                                          float* __restrict__ y_next = nullptr, double beta_next = 0.0) {
+                                                          float* __restrict__ y_next = nullptr, double beta_next = 0.0,
+                                                          int64_t slab_stride = 0) {
   if (scal->stopped != 0) return;
   __shared__ f32x4 lds[RG][RQ];
   __shared__ double dl[4 * 4];
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256) void fista_update_kernel(const float* __restri
     col = col0 + 4 * q;
     owner = (grp == 0) && (col < n);
     if constexpr (FROM_SLABS) {
-      const f32x4 tot = reduce_slab_block(slabs, nslabs, n, col0, lds);
+      const f32x4 tot = reduce_slab_block(slabs, nslabs, n, col0, lds, slab_stride);
       g[0] = tot.x; g[1] = tot.y; g[2] = tot.z; g[3] = tot.w;
     } else if (owner) {
       const f32x4 t = *reinterpret_cast<const f32x4*>(gbuf + col);
@@ -294,6 +296,13 @@ __global__ __launch_bounds__(64) void fista_finalize_kernel(const double* __rest
   if (prm.tol_step > 0.0 && step < prm.tol_step) stop = STOP_STEP;
   if (stop == STOP_NONE && prm.tol_ratio > 0.0 && ratio < prm.tol_ratio) stop = STOP_RATIO;
   scal->stopped = stop;
+}
+
+// y = (float)(x_cur + beta (x_cur - x_prev)) as one fp32 vector (entry of a lockstep multi-lambda run).
+__global__ __launch_bounds__(256) void form_y_kernel(const double* __restrict__ x_cur, const double* __restrict__ x_prev,
+                                                     double beta, float* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = (float)form_y(x_cur[i], x_prev[i], beta);
 }
 
 // Plain runs (no adaptive restart, no stopping tolerance): t_k and beta_k do not depend on the data, the host hands

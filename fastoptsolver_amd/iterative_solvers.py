@@ -384,3 +384,39 @@ def fista_delta(A, b, reg_type: str, alpha1: float, alpha2: float, delta: float,
                 grad_tol_check=False, history=history, history_obj=obj, check_every=check_every)
     x_k = _core.from_device_vec(st.x_tensor(), like)
     return (x_k, history) if return_history else x_k
+
+
+# ---------------------------------------------------------------------
+# Regularisation path (extension)
+# ---------------------------------------------------------------------
+def fista_path(A, b, alphas, t_init_factor: float = 1.0, max_iter: int = 500, *, delta=None, L=None, dtype=None):
+    """Solve the same (A, b) for several regularisation weights at once.
+
+    ``alphas`` is a sequence of ``(alpha1, alpha2)`` pairs.  The result is the list of solutions that
+    ``fista(A, b, ..., alpha1, alpha2, t_init_factor=t_init_factor, max_iter=max_iter, L=L)`` (or ``fista_delta``
+    when ``delta`` is given) would return one by one - same iterates - but up to four weights advance in lockstep and
+    every iteration reads A from HBM once for all of them (multi-vector form of the single-pass kernel; shapes
+    without such a kernel simply run one by one).  L is estimated once (one power iteration, one draw from the global
+    NumPy stream) unless given."""
+    reset_metrics()
+    if delta is not None:
+        assert delta > 2, "In FISTA-Δ, delta must be > 2 for convergence (course requirement)"
+    prob = _core.as_problem(A, b, dtype)
+    like = prob.like
+    L_val = estimate_lipschitz(prob) if L is None else float(L)
+    mode = _lib.MODE_FISTA if delta is None else _lib.MODE_DELTA
+    handles = []
+    for a1, a2 in alphas:
+        st = _core.Fista(prob)
+        st.reset(t_init_factor / (L_val + (a2 if a2 > 0 else 0.0)), a1, a2, mode=mode, delta=delta or 0.0)
+        handles.append(st)
+    gtimer = _EventTimer(grad_call_times)
+    for i in range(0, len(handles), 4):
+        group = handles[i:i + 4]
+        ev = gtimer.start()
+        if len(group) == 1 or not _core.run_multi(group, max_iter):
+            for st in group:
+                st.run(max_iter)
+        gtimer.stop(ev, max_iter)
+    gtimer.flush()
+    return [_core.from_device_vec(st.x_tensor(), like) for st in handles]

@@ -134,6 +134,12 @@ int fos_fista_run(fos_fista* f, int iters);
  * DUAL kernel; otherwise FOS_ERR_UNSUPPORTED and the caller drives the split form below.  Enqueues only. */
 int64_t fos_fista_history_workspace(fos_fista* f, int iters);
 int fos_fista_run_history(fos_fista* f, int iters, double* x_hist, double* hist, void* work);
+/* Regularisation path: nv <= 4 state machines bound to the SAME fos_problem (different alpha1 / alpha2 / tau) advance
+ * `iters` plain iterations in lockstep; every iteration reads A from HBM once for all of them (multi-vector form of
+ * the single-pass kernel).  Results are identical to running each handle with fos_fista_run.  FOS_ERR_UNSUPPORTED when
+ * the shape has no multi-vector kernel (n > 8192, bf16, two-pass path) or a handle needs data-dependent control: the
+ * caller then runs the handles one by one.  SURVEY.md 8(f) rank 3. */
+int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters);
 /* Split form for host-driven control (grad-norm stop :179, backtracking :183-197, sharded runs):
  *   fos_fista_grad    gbuf[0..n) = A^T (A y_k - b) (WITHOUT alpha2*y), gbuf[n] = ||A y_k - b||^2 (float)
  *   fos_fista_update  prox + momentum from gbuf (after an optional all-reduce of gbuf[0..n]) */

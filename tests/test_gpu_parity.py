@@ -590,3 +590,32 @@ def test_large_ragged_n_is_padded_onto_the_fused_path(fos):
     s = fos.LBFGSSolver("ridge", 0.0, 1.0, max_iter=8).fit(prob, None)
     s_ref = orc.LBFGSSolver("ridge", 0.0, 1.0, max_iter=8).fit(A64, b64)
     assert s.x_.shape == (n,) and _data.rel(s.x_, s_ref.x_) < 2e-5
+
+
+@pytest.mark.parametrize("nlam", [2, 3, 4, 6])
+def test_fista_path_equals_one_by_one(fos, nlam):
+    """Multi-lambda lockstep run (one pass over A per iteration for up to 4 weights) == independent solves."""
+    A, b, fx = _data.problem("aligned")
+    prob = fos.prepare(A, b)
+    lam = float(np.max(np.abs(A.T @ b)))
+    L = float(fx["aligned/L"])
+    alphas = [(lam * 0.3 * 0.5 ** i, 0.5 if i % 2 else 0.0) for i in range(nlam)]
+    xs = fos.fista_path(prob, None, alphas, max_iter=40, L=L)
+    assert len(xs) == nlam
+    for (a1, a2), x in zip(alphas, xs):
+        x_one = fos.fista(prob, None, "elasticnet", a1, a2, max_iter=40, L=L)
+        x_ref = orc.fista(A, b, "elasticnet", a1, a2, max_iter=40, L=L)
+        assert _data.rel(x, x_one) < 1e-9, (a1, a2)          # same arithmetic, different kernel instantiation
+        assert _data.rel(x, x_ref) < TOL, (a1, a2)
+    xd = fos.fista_path(prob, None, alphas[:2], max_iter=30, L=L, delta=3.0)
+    assert _data.rel(xd[1], orc.fista_delta(A, b, "elasticnet", alphas[1][0], alphas[1][1], 3.0, max_iter=30, L=L)) < TOL
+
+
+def test_fista_path_falls_back_on_shapes_without_multi_kernel(fos):
+    A, b, fx = _data.problem("ragged")          # two-pass path: no multi-vector kernel -> one by one, same answers
+    lam = float(np.max(np.abs(A.T @ b)))
+    L = float(fx["ragged/L"])
+    alphas = [(0.2 * lam, 0.0), (0.05 * lam, 0.5)]
+    xs = fos.fista_path(A, b, alphas, max_iter=25, L=L)
+    for (a1, a2), x in zip(alphas, xs):
+        assert _data.rel(x, orc.fista(A, b, "elasticnet", a1, a2, max_iter=25, L=L)) < TOL
