@@ -186,6 +186,8 @@ int ensure_workspace(fos_problem* p) {
   const int need_slabs = p->nslabs;
   if (need_slabs > p->slab_cap) {
     if (p->slabs) (void)hipFree(p->slabs);
+    p->slabs = nullptr;
+    p->slab_cap = 0;
     HIP_TRY(hipMalloc(&p->slabs, (size_t)need_slabs * p->n * sizeof(float)));
     p->slab_cap = need_slabs;
   }
@@ -193,6 +195,8 @@ int ensure_workspace(fos_problem* p) {
   if (need_rr > p->rr_cap) {
     if (p->rr_part) (void)hipFree(p->rr_part);
     if (p->rr2_part) (void)hipFree(p->rr2_part);
+    p->rr_part = p->rr2_part = nullptr;
+    p->rr_cap = 0;
     HIP_TRY(hipMalloc(&p->rr_part, (size_t)need_rr * sizeof(double)));
     HIP_TRY(hipMalloc(&p->rr2_part, (size_t)need_rr * sizeof(double)));
     p->rr_cap = need_rr;
@@ -295,11 +299,11 @@ __global__ void xp_pack_kernel(const float* __restrict__ X, int n, int n_pad, in
 }
 
 int ensure_batch_workspace(fos_problem* p) {
-  if (p->xp) return FOS_OK;
+  if (p->xp && p->q_part && p->bt_out) return FOS_OK;     // all three or nothing: a failed attempt is retried cleanly
   p->n_pad = (p->n + fos::BT_COLS - 1) / fos::BT_COLS * fos::BT_COLS;
-  HIP_TRY(hipMalloc(&p->xp, (size_t)p->n_pad * fos::BT_NV * sizeof(float)));
-  HIP_TRY(hipMalloc(&p->q_part, (size_t)(3 * p->ncu + 8) * fos::BT_NV * sizeof(double)));
-  HIP_TRY(hipMalloc(&p->bt_out, 128 * sizeof(double)));
+  if (!p->xp) HIP_TRY(hipMalloc(&p->xp, (size_t)p->n_pad * fos::BT_NV * sizeof(float)));
+  if (!p->q_part) HIP_TRY(hipMalloc(&p->q_part, (size_t)(3 * p->ncu + 8) * fos::BT_NV * sizeof(double)));
+  if (!p->bt_out) HIP_TRY(hipMalloc(&p->bt_out, 128 * sizeof(double)));
   return FOS_OK;
 }
 
@@ -515,25 +519,35 @@ int fos_power_iter(fos_problem* p, float* v_inout, int n_iter, double tol, doubl
   // v = v0 / ||v0||   (iterative_solvers.py:51)
   hipLaunchKernelGGL(fos::power_normalize_kernel, dim3(1), dim3(1024), 0, p->stream, v_inout, (int)p->n, v, Lh + n_iter);
   LAUNCH_CHECK();
-  for (int it = 0; it < n_iter; ++it) {
-    YSource ys{v, nullptr, nullptr, nullptr, nullptr};
-    int n_rr = 0, rc;
-    if ((rc = launch_pass(p, ys, nullptr, true, &n_rr))) return rc;                       // w = A^T (A v)   :54
-    if ((rc = launch_slab_reduce(p, n_rr, p->gbuf, nullptr, nullptr))) return rc;
-    hipLaunchKernelGGL(fos::power_normalize_kernel, dim3(1), dim3(1024), 0, p->stream, p->gbuf, (int)p->n, v,
-                       Lh + it);                                                         // L = ||w||, v = w/L :55-56
-    LAUNCH_CHECK();
-  }
+  // The reference breaks as soon as |L - prev| < tol (:57).  The iterations are enqueued in chunks; after each chunk
+  // the L values are read back and the break rule is replayed on the host, so a matrix with a dominant eigenvalue
+  // stops after a chunk instead of running all n_iter passes (the answer is the same either way).
   std::vector<double> hL(n_iter);
-  HIP_TRY(hipMemcpyAsync(hL.data(), Lh, (size_t)n_iter * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  const int chunk = 16;
+  double prev = 0.0;
+  int used = n_iter, done = 0;
+  bool hit = false;
+  while (done < n_iter && !hit) {
+    const int todo = std::min(chunk, n_iter - done);
+    for (int it = done; it < done + todo; ++it) {
+      YSource ys{v, nullptr, nullptr, nullptr, nullptr};
+      int n_rr = 0, rc;
+      if ((rc = launch_pass(p, ys, nullptr, true, &n_rr))) return rc;                       // w = A^T (A v)   :54
+      if ((rc = launch_slab_reduce(p, n_rr, p->gbuf, nullptr, nullptr))) return rc;
+      hipLaunchKernelGGL(fos::power_normalize_kernel, dim3(1), dim3(1024), 0, p->stream, p->gbuf, (int)p->n, v,
+                         Lh + it);                                                         // L = ||w||, v = w/L :55-56
+      LAUNCH_CHECK();
+    }
+    HIP_TRY(hipMemcpyAsync(hL.data() + done, Lh + done, (size_t)todo * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    for (int it = done; it < done + todo; ++it) {      // |L - prev| < tol -> break   :57
+      if (std::fabs(hL[it] - prev) < tol) { used = it + 1; hit = true; break; }
+      prev = hL[it];
+    }
+    done += todo;
+  }
   HIP_TRY(hipMemcpyAsync(v_inout, v, (size_t)p->n * sizeof(float), hipMemcpyDeviceToDevice, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
-  double prev = 0.0;
-  int used = n_iter;
-  for (int it = 0; it < n_iter; ++it) {           // |L - prev| < tol -> break   :57
-    if (std::fabs(hL[it] - prev) < tol) { used = it + 1; break; }
-    prev = hL[it];
-  }
   *L_out = hL[used - 1];
   if (iters_out) *iters_out = used;
   return FOS_OK;
