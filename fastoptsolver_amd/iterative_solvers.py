@@ -295,25 +295,43 @@ def ista(x0, g, grad_g, prox_h, L, backtracking: bool = False, eta: float = 0.5,
         x = _core.from_device_vec(st.x_tensor(), x0)
         return (x, log) if return_history else x
 
-    # ---- generic callables on device tensors ----
+    # ---- generic callables ----
+    # The loop's own vector arithmetic runs on the device.  The callables are the caller's code: they get float32
+    # device tensors; a callable written for ndarrays (what a user of the reference has: closures over a NumPy A)
+    # is detected on its first call and from then on fed float64 ndarrays, its result moved back to the device.
     from .operators import vec_axpby, vec_stats
     x = _core.to_device_vec(x0).clone()                                        # ref:79
+    wants_numpy = {}
+
+    def call(fn, *args):
+        key = id(fn)
+        if not wants_numpy.get(key, False):
+            try:
+                return fn(*args)
+            except (TypeError, RuntimeError, ValueError, AttributeError):
+                if _core.is_tensor(x0):
+                    raise
+                wants_numpy[key] = True
+        host = [a.detach().to("cpu", torch.float64).numpy() if _core.is_tensor(a) else a for a in args]
+        out = fn(*host)
+        return _core.to_device_vec(out) if isinstance(out, np.ndarray) and out.ndim == 1 else out
+
     log = {"x": [_core.from_device_vec(x, x0)], "t": [t], "delta": []} if return_history else None
     gtimer = _EventTimer(grad_call_times)
     for _ in range(max_iter):
         ev = gtimer.start()
-        grad = grad_g(x)                                                        # ref:87-89
+        grad = _core.to_device_vec(call(grad_g, x))                             # ref:87-89
         gtimer.stop(ev)
         if backtracking:                                                        # ref:92-108
             bt_steps = 0
             ls_t0 = time.perf_counter()
             t_k = t
-            gx = float(g(x))
+            gx = float(call(g, x))
             while True:
-                x_new = prox_h(vec_axpby(1.0, x, -t_k, grad), t_k)
+                x_new = _core.to_device_vec(call(prox_h, vec_axpby(1.0, x, -t_k, grad), t_k))
                 diff = vec_axpby(1.0, x_new, -1.0, x)
                 gd = vec_stats(None, grad, diff)[1]
-                if float(g(x_new)) <= gx + C * gd:
+                if float(call(g, x_new)) <= gx + C * gd:
                     break
                 t_k *= eta
                 bt_steps += 1
@@ -321,7 +339,7 @@ def ista(x0, g, grad_g, prox_h, L, backtracking: bool = False, eta: float = 0.5,
             ls_call_iters.append(bt_steps)
             t = t_k
         else:
-            x_new = prox_h(vec_axpby(1.0, x, -t, grad), t)                      # ref:110-111
+            x_new = _core.to_device_vec(call(prox_h, vec_axpby(1.0, x, -t, grad), t))   # ref:110-111
             diff = vec_axpby(1.0, x_new, -1.0, x)
         delta = math.sqrt(vec_stats(None, None, diff)[2])                        # ref:114
         x = x_new

@@ -619,3 +619,20 @@ def test_fista_path_falls_back_on_shapes_without_multi_kernel(fos):
     xs = fos.fista_path(A, b, alphas, max_iter=25, L=L)
     for (a1, a2), x in zip(alphas, xs):
         assert _data.rel(x, orc.fista(A, b, "elasticnet", a1, a2, max_iter=25, L=L)) < TOL
+
+
+def test_ista_with_the_reference_users_numpy_closures(fos):
+    """What a user of the reference actually passes to ista(): closures over a NumPy A (ref:65-77 call sites).  They
+    must keep working unchanged (fed ndarrays), with the same answers as the fused path."""
+    A, b, fx = _data.problem("tiny")
+    a1 = 0.1 * float(np.max(np.abs(A.T @ b)))
+    L = float(fx["tiny/ista/L"])
+    g = lambda x: 0.5 * float((A @ x - b) @ (A @ x - b))                       # noqa: E731
+    grad_g = lambda x: A.T @ (A @ x - b)                                      # noqa: E731
+    prox_h = lambda v, t: np.sign(v) * np.maximum(np.abs(v) - t * a1, 0.0)    # noqa: E731
+    for kw, name in ((dict(), "fixed"), (dict(backtracking=True, t_init_factor=2.0), "bt2")):
+        x, log = fos.ista(np.zeros(16), g, grad_g, prox_h, L, max_iter=40, return_history=True, **kw)
+        key = f"tiny/ista/l1/{name}"
+        assert isinstance(x, np.ndarray) and x.dtype == np.float64
+        assert _data.rel(x, fx[key + "/x"]) < TOL, key
+        assert len(log["x"]) == 41 and len(log["delta"]) == 40
