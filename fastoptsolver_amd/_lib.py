@@ -46,6 +46,7 @@ SIGNATURES = {
     "fos_residual_batch": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "fos_power_iter": (_i32, [_vp, _vp, _i32, _f64, C.POINTER(_f64), C.POINTER(_i32)]),
     "fos_prox_l1": (_i32, [_vp, _f32, _vp, _i64, _vp]),
+    "fos_prox_l1_vec": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "fos_prox_elastic_net": (_i32, [_vp, _f32, _f32, _f32, _vp, _i64, _vp]),
     "fos_fista_create": (_i32, [_vp, C.POINTER(_vp)]),
     "fos_fista_destroy": (_i32, [_vp]),

@@ -561,6 +561,14 @@ int fos_prox_l1(const float* v, float thr, float* out, int64_t n, void* stream) 
   return FOS_OK;
 }
 
+int fos_prox_l1_vec(const float* v, const float* thr, float* out, int64_t n, void* stream) {
+  if (n == 0) return FOS_OK;
+  if (!v || !thr || !out || n < 0) return fail(FOS_ERR_ARG, "fos_prox_l1_vec: bad argument");
+  hipLaunchKernelGGL(fos::prox_l1_vec_kernel, dim3(grid_1d(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, v, thr, out, n);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
 int fos_prox_elastic_net(const float* v, float tau, float alpha1, float alpha2, float* out, int64_t n, void* stream) {
   if (n == 0) return FOS_OK;
   if (!v || !out || n < 0) return fail(FOS_ERR_ARG, "fos_prox_elastic_net: bad argument");

@@ -432,6 +432,12 @@ __global__ __launch_bounds__(256) void prox_l1_kernel(const float* __restrict__ 
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
     out[i] = soft_threshold(v[i], thr);
 }
+// per-element threshold (the reference's prox_l1 broadcasts an array-valued tau: prox_operators.py:8)
+__global__ __launch_bounds__(256) void prox_l1_vec_kernel(const float* __restrict__ v, const float* __restrict__ thr,
+                                                         float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = soft_threshold(v[i], thr[i]);
+}
 __global__ __launch_bounds__(256) void prox_enet_kernel(const float* __restrict__ v, float tau, float a1, float a2,
                                                        float* __restrict__ out, int64_t n) {
   const float thr = tau * a1, inv = 1.0f + tau * a2;

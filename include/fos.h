@@ -112,6 +112,7 @@ int fos_power_iter(fos_problem* p, float* v_inout, int n_iter, double tol, doubl
 
 /* ---- stand-alone prox (K3), prox_operators.py:3-8 and :10-16 --------------------------------------- */
 int fos_prox_l1(const float* v, float thr, float* out, int64_t n, void* stream);
+int fos_prox_l1_vec(const float* v, const float* thr, float* out, int64_t n, void* stream);   /* per-element threshold */
 int fos_prox_elastic_net(const float* v, float tau, float alpha1, float alpha2, float* out, int64_t n, void* stream);
 
 /* ---- FISTA / FISTA-delta / ISTA state machine ------------------------------------------------------- */

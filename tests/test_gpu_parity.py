@@ -119,6 +119,11 @@ def test_prox_kernels(fos):
     t = fos.prox_l1(_dev(v), 0.7)
     assert isinstance(t, torch.Tensor) and t.is_cuda and t.numel() == v.size
     assert fos.prox_l1(np.zeros(0, dtype=np.float32), 0.1).size == 0
+    # array-valued tau, as the reference's broadcasting expression allows
+    thr = np.abs(np.random.default_rng(1).standard_normal(v.size)).astype(np.float32)
+    assert np.allclose(fos.prox_l1(v, thr), orc.prox_l1(v.astype(np.float64), thr.astype(np.float64)), rtol=1e-6, atol=1e-7)
+    with pytest.raises(ValueError):
+        fos.prox_l1(v, thr[:5])
 
 
 def test_compute_objective(fos):
