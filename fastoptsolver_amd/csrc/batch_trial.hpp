@@ -218,4 +218,236 @@ __global__ __launch_bounds__(BT_THREADS, 2) void residual_batch_mfma_kernel(cons
   if (tid < BT_NV) q_part[(int64_t)blockIdx.x * BT_NV + tid] = (wsum[0][tid] + wsum[1][tid]) + (wsum[2][tid] + wsum[3][tid]);
 }
 
+
+// =========================================================================================================
+// bf16 A: the same batched residual on v_mfma_f32_16x16x32_bf16 (BASELINE config 5: "CDNA4 bf16 MFMA path").
+//
+// The MFMA needs bf16 operands on both sides, but rounding the candidate vectors to bf16 (8 mantissa bits) would put
+// 4e-3 relative noise on ||A dlt||^2.  Each candidate is therefore split into THREE bf16 terms
+//     d = hi + mid + lo,   hi = bf16(d), mid = bf16(d - hi), lo = bf16(d - hi - mid)      (24 mantissa bits)
+// and the three products A*hi, A*mid, A*lo accumulate into the SAME fp32 D tile: fp32-equivalent accuracy at bf16
+// MFMA rate (16 cycles per 16x16x32 step; 12 MFMAs per 16 KiB tile per wave against 16 f32 MFMAs of 32 cycles).
+// Tile = 64 rows x 128 bf16 columns = the same 16 KiB / 256 B-per-row staging as the fp32 kernel.
+//
+// Candidate block layout ("Xq"), bf16:  for column k, candidate j, part p (0 hi, 1 mid, 2 lo)
+//   Xq[ (((k/32)*3 + p)*4 + (k%32)/8) * 128 + j*8 + (k%8) ]
+// i.e. per 32-column k-step and part a [q = 4][j = 16][e = 8] cube: one 16-byte read per lane, 1 KiB per wave.
+// =========================================================================================================
+constexpr int BQ_COLS = 128;                         // Xq is zero-padded to a multiple of this many columns
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __host__ inline int64_t xq_index(int64_t k, int j, int part) {
+  return (((k / 32) * 3 + part) * 4 + (k % 32) / 8) * 128 + (int64_t)j * 8 + (k % 8);
+}
+
+__device__ inline unsigned short f32_to_bf16_rn(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);      // finite inputs only (differences of iterates)
+}
+__device__ inline float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+// Candidate generation for the bf16 path: same sums as fista_trial_batch_kernel, dlt_j written as three bf16 terms.
+__global__ __launch_bounds__(256) void fista_trial_batch_bf16_kernel(const float* __restrict__ gbuf, int n, int n_pad,
+                                                                    const double* __restrict__ x_cur,
+                                                                    const double* __restrict__ x_prev,
+                                                                    const FistaScalars* __restrict__ scal,
+                                                                    FistaParams prm, double t0, double eta, int nv,
+                                                                    unsigned short* __restrict__ xq,
+                                                                    double* __restrict__ part) {
+  __shared__ double red[4][BT_W];
+  const double beta = scal->beta;
+  double gd[BT_NV], dd[BT_NV], nz[BT_NV];
+#pragma unroll
+  for (int j = 0; j < BT_NV; ++j) { gd[j] = 0.0; dd[j] = 0.0; nz[j] = 0.0; }
+  double g2 = 0.0, y2 = 0.0;
+  for (int col = blockIdx.x * 256 + threadIdx.x; col < n_pad; col += gridDim.x * 256) {
+    double y = 0.0, gf = 0.0;
+    if (col < n) {
+      y = form_y(x_cur[col], x_prev[col], beta);
+      gf = (double)gbuf[col];
+      if (prm.prox_kind == PROX_L1 && prm.alpha2 > 0.0) gf += prm.alpha2 * y;
+      g2 += gf * gf;
+      y2 += y * y;
+    }
+    double t = t0;
+#pragma unroll
+    for (int j = 0; j < BT_NV; ++j) {
+      double d = 0.0;
+      if (col < n && j < nv) {
+        const double v = y - t * gf;
+        double xt = prm.alpha1 > 0.0 ? soft_threshold(v, t * prm.alpha1) : v;
+        if (prm.prox_kind == PROX_ENET) xt *= 1.0 / (1.0 + t * prm.alpha2);
+        d = xt - y;
+        gd[j] += gf * d;
+        dd[j] += d * d;
+        nz[j] += (d != 0.0) ? 1.0 : 0.0;
+      }
+      const float df = (float)d;
+      const unsigned short hi = f32_to_bf16_rn(df);
+      const float r1 = df - bf16_to_f32(hi);
+      const unsigned short mid = f32_to_bf16_rn(r1);
+      const unsigned short lo = f32_to_bf16_rn(r1 - bf16_to_f32(mid));
+      xq[xq_index(col, j, 0)] = hi;
+      xq[xq_index(col, j, 1)] = mid;
+      xq[xq_index(col, j, 2)] = lo;
+      t *= eta;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto put = [&](double v, int slot) {
+    v = wave_sum(v);
+    if (lane == 0) red[wave][slot] = v;
+  };
+#pragma unroll
+  for (int j = 0; j < BT_NV; ++j) { put(gd[j], j); put(dd[j], BT_NV + j); put(nz[j], 2 * BT_NV + j); }
+  put(g2, 3 * BT_NV);
+  put(y2, 3 * BT_NV + 1);
+  __syncthreads();
+  if (threadIdx.x < BT_W)
+    part[(int64_t)blockIdx.x * BT_W + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// Plain [n][16] fp32 candidates -> Xq (three bf16 terms each); stand-alone entry / tests.
+__global__ void xq_pack_kernel(const float* __restrict__ X, int n, int n_pad, int nv, unsigned short* __restrict__ xq) {
+  for (int col = blockIdx.x * 256 + threadIdx.x; col < n_pad; col += gridDim.x * 256)
+    for (int j = 0; j < BT_NV; ++j) {
+      const float df = (col < n && j < nv) ? X[(int64_t)col * BT_NV + j] : 0.f;
+      const unsigned short hi = f32_to_bf16_rn(df);
+      const float r1 = df - bf16_to_f32(hi);
+      const unsigned short mid = f32_to_bf16_rn(r1);
+      xq[xq_index(col, j, 0)] = hi;
+      xq[xq_index(col, j, 1)] = mid;
+      xq[xq_index(col, j, 2)] = f32_to_bf16_rn(r1 - bf16_to_f32(mid));
+    }
+}
+
+// q_part[wg][j] = sum over this workgroup's rows of (A_i . X_j - use_b*b_i)^2, A in bf16.
+// RB = 16-row blocks per wave (the candidate fragments read from LDS are reused for RB row blocks: X is 96 bytes per
+// column against 32 bytes of A per row block, so LDS traffic per byte of A falls with RB); COLS = bf16 columns per tile.
+// Requirements: n % 8 == 0, lda % 8 == 0, A 16-byte aligned, Xq zero-padded to n_pad (a multiple of 128).
+template <int RB, int COLS>
+__global__ __launch_bounds__(BT_THREADS) void residual_batch_mfma_bf16_kernel(
+    const bf16_t* __restrict__ A, int64_t lda, const float* __restrict__ b, int use_b, int64_t m, int n,
+    const unsigned short* __restrict__ xq, int64_t groups_per_wg, double* __restrict__ q_part) {
+  constexpr int ROWS = 64 * RB;
+  constexpr int STRIDE = COLS + 8;
+  constexpr int CPR = COLS / 8;                               // 16-byte chunks per tile row
+  constexpr int X_TILE = COLS * BT_NV * 3;
+  constexpr int A_LOADS = ROWS * CPR / BT_THREADS;
+  constexpr int X_CHUNKS = X_TILE / 8;
+  constexpr int X_LOADS = (X_CHUNKS + BT_THREADS - 1) / BT_THREADS;
+  __shared__ __attribute__((aligned(16))) unsigned short a_s[2][ROWS][STRIDE];
+  __shared__ __attribute__((aligned(16))) unsigned short x_s[2][X_TILE];
+  __shared__ double wsum[4][BT_NV];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t ngroups = (m + ROWS - 1) / ROWS;
+  const int64_t g_lo = (int64_t)blockIdx.x * groups_per_wg;
+  int64_t g_hi = g_lo + groups_per_wg;
+  if (g_hi > ngroups) g_hi = ngroups;
+  const int ktiles = (n + COLS - 1) / COLS;
+  const int64_t ntiles = (g_hi > g_lo ? (g_hi - g_lo) : 0) * ktiles;
+
+  u32x4 areg[2][A_LOADS];
+  u32x4 xreg[2][X_LOADS];
+  auto load_tile = [&](int set, int64_t t) {
+    const int64_t grp = g_lo + t / ktiles;
+    const int kt = (int)(t % ktiles);
+    const int64_t row0 = grp * ROWS;
+    const int col0 = kt * COLS;
+#pragma unroll
+    for (int u = 0; u < A_LOADS; ++u) {
+      const int f = u * BT_THREADS + tid;
+      int64_t row = row0 + f / CPR;
+      int col = col0 + 8 * (f % CPR);
+      if (row >= m) row = m - 1;
+      if (col >= n) col = n - 8;                  // clamped columns meet zero rows of Xq
+      areg[set][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(A + row * lda + col));
+    }
+#pragma unroll
+    for (int u = 0; u < X_LOADS; ++u) {
+      int c = u * BT_THREADS + tid;
+      if (c >= X_CHUNKS) c = X_CHUNKS - 1;        // branch-free; the surplus lanes do not store
+      xreg[set][u] = *reinterpret_cast<const u32x4*>(xq + (int64_t)kt * X_TILE + 8 * c);
+    }
+  };
+  auto store_tile = [&](int set, int buf) {
+#pragma unroll
+    for (int u = 0; u < A_LOADS; ++u) {
+      const int f = u * BT_THREADS + tid;
+      *reinterpret_cast<u32x4*>(&a_s[buf][f / CPR][8 * (f % CPR)]) = areg[set][u];
+    }
+#pragma unroll
+    for (int u = 0; u < X_LOADS; ++u) {
+      const int c = u * BT_THREADS + tid;
+      if (c < X_CHUNKS) *reinterpret_cast<u32x4*>(&x_s[buf][8 * c]) = xreg[set][u];
+    }
+  };
+  f32x4 acc[RB], acc_odd[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) { acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_odd[rb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  double qsum = 0.0;
+  auto compute_tile = [&](int buf, int64_t t) {
+#pragma unroll
+    for (int ks = 0; ks < COLS / 32; ++ks) {
+      const int xo = (lane >> 4) * 128 + (lane & 15) * 8;
+      const bf16x8 xh = *reinterpret_cast<const bf16x8*>(&x_s[buf][(ks * 3 + 0) * 512 + xo]);
+      const bf16x8 xm = *reinterpret_cast<const bf16x8*>(&x_s[buf][(ks * 3 + 1) * 512 + xo]);
+      const bf16x8 xl = *reinterpret_cast<const bf16x8*>(&x_s[buf][(ks * 3 + 2) * 512 + xo]);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const bf16x8 a8 =
+            *reinterpret_cast<const bf16x8*>(&a_s[buf][16 * (wave * RB + rb) + (lane & 15)][32 * ks + 8 * (lane >> 4)]);
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, xh, acc[rb], 0, 0, 0);
+        acc_odd[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, xm, acc_odd[rb], 0, 0, 0);
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, xl, acc[rb], 0, 0, 0);
+      }
+    }
+    if ((t + 1) % ktiles == 0) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        acc[rb] += acc_odd[rb];
+        const int64_t row0 = (g_lo + t / ktiles) * ROWS + 16 * (wave * RB + rb) + 4 * (lane >> 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = row0 + r;
+          if (row < m) {
+            float v = acc[rb][r];
+            if (use_b) v -= b[row];
+            qsum += (double)v * (double)v;
+          }
+        }
+        acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc_odd[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+
+  if (ntiles > 0) {
+    const int64_t last = ntiles - 1;
+    auto clampt = [&](int64_t t) { return t < last ? t : last; };
+    load_tile(0, 0);
+    store_tile(0, 0);
+    load_tile(1, clampt(1));
+    __syncthreads();
+    int64_t t = 0;
+    for (; t + 2 <= ntiles; t += 2) {
+      load_tile(0, clampt(t + 2));
+      compute_tile(0, t);
+      store_tile(1, 1);
+      __syncthreads();
+      load_tile(1, clampt(t + 3));
+      compute_tile(1, t + 1);
+      store_tile(0, 0);
+      __syncthreads();
+    }
+    if (t < ntiles) compute_tile(0, t);
+  }
+  qsum += __shfl_xor(qsum, 16, 64);
+  qsum += __shfl_xor(qsum, 32, 64);
+  if (lane < BT_NV) wsum[wave][lane] = qsum;
+  __syncthreads();
+  if (tid < BT_NV) q_part[(int64_t)blockIdx.x * BT_NV + tid] = (wsum[0][tid] + wsum[1][tid]) + (wsum[2][tid] + wsum[3][tid]);
+}
+
 }  // namespace fos

@@ -300,23 +300,46 @@ __global__ void xp_pack_kernel(const float* __restrict__ X, int n, int n_pad, in
 
 int ensure_batch_workspace(fos_problem* p) {
   if (p->xp && p->q_part && p->bt_out) return FOS_OK;     // all three or nothing: a failed attempt is retried cleanly
-  p->n_pad = (p->n + fos::BT_COLS - 1) / fos::BT_COLS * fos::BT_COLS;
-  if (!p->xp) HIP_TRY(hipMalloc(&p->xp, (size_t)p->n_pad * fos::BT_NV * sizeof(float)));
+  const int64_t tile_cols = p->dtype == FOS_BF16 ? fos::BQ_COLS : fos::BT_COLS;
+  p->n_pad = (p->n + tile_cols - 1) / tile_cols * tile_cols;
+  // fp32: Xp, one float per (column, candidate); bf16: Xq, three bf16 terms per (column, candidate)
+  const size_t per_entry = p->dtype == FOS_BF16 ? 3 * sizeof(unsigned short) : sizeof(float);
+  if (!p->xp) HIP_TRY(hipMalloc(&p->xp, (size_t)p->n_pad * fos::BT_NV * per_entry));
   if (!p->q_part) HIP_TRY(hipMalloc(&p->q_part, (size_t)(3 * p->ncu + 8) * fos::BT_NV * sizeof(double)));
   if (!p->bt_out) HIP_TRY(hipMalloc(&p->bt_out, 128 * sizeof(double)));
   return FOS_OK;
 }
 
+// bf16 variants of the batched kernel: (row blocks per wave, tile columns), rows per workgroup, workgroups per CU.
+// Measured at 65536 x 8192 (tools/bench_bq.py): <1,128> 208.6 us, <2,64> 213.5 us, <2,128> 166.6 us (80.6 % of HBM),
+// <4,64> 170.4 us.  The 128-row tile halves the LDS re-reads of the candidate fragments per byte of A; the 64-row
+// tile is kept for short problems, where it gives twice as many workgroups.
+typedef void (*Bf16Batch)(const fos::bf16_t*, int64_t, const float*, int, int64_t, int, const unsigned short*, int64_t, double*);
+struct Bf16BatchVariant { Bf16Batch fn; int rows; int wg_per_cu; };
+const Bf16BatchVariant kBf16Batch[] = {
+    {fos::residual_batch_mfma_bf16_kernel<1, 128>, 64, 2},
+    {fos::residual_batch_mfma_bf16_kernel<2, 128>, 128, 1},
+};
+
 // q[j] = ||A Xp_j - use_b*b||^2 -> out16 (device); Xp already in p->xp.
 int launch_residual_batch(fos_problem* p, int use_b, double* out16) {
-  const int64_t ngroups = (p->m + fos::BT_ROWS - 1) / fos::BT_ROWS;
-  int64_t nwg = std::min<int64_t>(ngroups, 3 * (int64_t)p->ncu);
+  const bool is_bf16 = p->dtype == FOS_BF16;
+  const int variant = p->m >= 128 * (int64_t)p->ncu ? 1 : 0;
+  const int rows = is_bf16 ? kBf16Batch[variant].rows : fos::BT_ROWS;
+  const int per_cu = is_bf16 ? kBf16Batch[variant].wg_per_cu : 3;
+  const int64_t ngroups = (p->m + rows - 1) / rows;
+  int64_t nwg = std::min<int64_t>(ngroups, per_cu * (int64_t)p->ncu);
   const int64_t gpw = (ngroups + nwg - 1) / nwg;
   nwg = (ngroups + gpw - 1) / gpw;
   int rc = prof_mark(p, true);
   if (rc) return rc;
-  hipLaunchKernelGGL(fos::residual_batch_mfma_kernel, dim3((unsigned)nwg), dim3(fos::BT_THREADS), 0, p->stream,
-                     (const float*)p->A, p->lda, p->b, (use_b && p->b) ? 1 : 0, p->m, (int)p->n, p->xp, gpw, p->q_part);
+  if (is_bf16)
+    hipLaunchKernelGGL(kBf16Batch[variant].fn, dim3((unsigned)nwg), dim3(fos::BT_THREADS), 0, p->stream,
+                       (const fos::bf16_t*)p->A, p->lda, p->b, (use_b && p->b) ? 1 : 0, p->m, (int)p->n,
+                       (const unsigned short*)p->xp, gpw, p->q_part);
+  else
+    hipLaunchKernelGGL(fos::residual_batch_mfma_kernel, dim3((unsigned)nwg), dim3(fos::BT_THREADS), 0, p->stream,
+                       (const float*)p->A, p->lda, p->b, (use_b && p->b) ? 1 : 0, p->m, (int)p->n, p->xp, gpw, p->q_part);
   LAUNCH_CHECK();
   if ((rc = prof_mark(p, false))) return rc;
   hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->q_part, (int)nwg, fos::BT_NV, out16);
@@ -342,7 +365,7 @@ MultiLaunch find_multi(int64_t n, int nv) {
   return nullptr;
 }
 
-bool batch_supported(const fos_problem* p) { return p->path == 0 && p->dtype == FOS_F32; }
+bool batch_supported(const fos_problem* p) { return p->path == 0; }   // fp32: f32 MFMA; bf16: 3-term bf16 MFMA
 
 // A caller vector the fused prologue can read with 16-byte loads.
 int aligned_vec(fos_problem* p, const float* v, const float** out) {
@@ -502,11 +525,15 @@ int fos_residual_objective(fos_problem* p, const float* x, double* out3) {
 
 int fos_residual_batch(fos_problem* p, const float* X, int nv, int use_b, double* out16) {
   if (!p || !X || !out16 || nv < 1 || nv > fos::BT_NV) return fail(FOS_ERR_ARG, "fos_residual_batch: bad argument");
-  if (!batch_supported(p)) return fail(FOS_ERR_UNSUPPORTED, "fos_residual_batch: needs the fused fp32 path");
+  if (!batch_supported(p)) return fail(FOS_ERR_UNSUPPORTED, "fos_residual_batch: needs the fused path");
   int rc = ensure_batch_workspace(p);
   if (rc) return rc;
-  hipLaunchKernelGGL(xp_pack_kernel, dim3(grid_1d(p->n_pad, 256, 256)), dim3(256), 0, p->stream, X, (int)p->n,
-                     (int)p->n_pad, nv, p->xp);
+  if (p->dtype == FOS_BF16)
+    hipLaunchKernelGGL(fos::xq_pack_kernel, dim3(grid_1d(p->n_pad, 256, 256)), dim3(256), 0, p->stream, X, (int)p->n,
+                       (int)p->n_pad, nv, (unsigned short*)p->xp);
+  else
+    hipLaunchKernelGGL(xp_pack_kernel, dim3(grid_1d(p->n_pad, 256, 256)), dim3(256), 0, p->stream, X, (int)p->n,
+                       (int)p->n_pad, nv, p->xp);
   LAUNCH_CHECK();
   return launch_residual_batch(p, use_b, out16);
 }
@@ -1025,12 +1052,16 @@ int fos_fista_trial_batch(fos_fista* f, double t, double eta, int nv, double* ou
     return fail(FOS_ERR_ARG, "fos_fista_trial_batch: bad argument");
   fos_problem* p = f->p;
   { int rcf = flush_pending(f); if (rcf) return rcf; }
-  if (!batch_supported(p)) return fail(FOS_ERR_UNSUPPORTED, "fos_fista_trial_batch: needs the fused fp32 path");
+  if (!batch_supported(p)) return fail(FOS_ERR_UNSUPPORTED, "fos_fista_trial_batch: needs the fused path");
   int rc = ensure_batch_workspace(p);
   if (rc) return rc;
   const int grid = grid_1d(p->n_pad, 256, 64);
-  hipLaunchKernelGGL(fos::fista_trial_batch_kernel, dim3(grid), dim3(256), 0, p->stream, p->gbuf, (int)p->n,
-                     (int)p->n_pad, f->x_cur, f->x_prev, f->scal, f->prm, t, eta, nv, p->xp, p->part);
+  if (p->dtype == FOS_BF16)
+    hipLaunchKernelGGL(fos::fista_trial_batch_bf16_kernel, dim3(grid), dim3(256), 0, p->stream, p->gbuf, (int)p->n,
+                       (int)p->n_pad, f->x_cur, f->x_prev, f->scal, f->prm, t, eta, nv, (unsigned short*)p->xp, p->part);
+  else
+    hipLaunchKernelGGL(fos::fista_trial_batch_kernel, dim3(grid), dim3(256), 0, p->stream, p->gbuf, (int)p->n,
+                       (int)p->n_pad, f->x_cur, f->x_prev, f->scal, f->prm, t, eta, nv, p->xp, p->part);
   hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->part, grid, fos::BT_W, p->bt_out);
   LAUNCH_CHECK();
   HIP_TRY(hipMemcpyAsync(p->bt_out + 100, &f->scal->rr, sizeof(double), hipMemcpyDeviceToDevice, p->stream));

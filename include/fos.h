@@ -102,8 +102,9 @@ int fos_gemv_pair_f64(fos_problem* p, const double* y, double alpha2, float* gra
 int fos_residual_objective(fos_problem* p, const float* x, double* out3);
 
 /* Batched K5 on the matrix cores: out16[j] (device doubles) = ||A X_j - use_b*b||^2 for the nv <= 16 vectors stored as
- * the columns of X (n x 16 floats, row-major: X[k*16 + j]); one pass over A.  FOS_ERR_UNSUPPORTED on fallback-path
- * problems. */
+ * the columns of X (n x 16 floats, row-major: X[k*16 + j]); one pass over A.  fp32 A: v_mfma_f32_16x16x4_f32;
+ * bf16 A: v_mfma_f32_16x16x32_bf16 with each vector split into three bf16 terms (24 mantissa bits), so both keep
+ * fp32 accuracy.  FOS_ERR_UNSUPPORTED on fallback-path problems. */
 int fos_residual_batch(fos_problem* p, const float* X, int nv, int use_b, double* out16);
 
 /* Power iteration, iterative_solvers.py:45-60.  v_inout: start vector (n floats, need not be normalised),
@@ -157,7 +158,8 @@ int fos_fista_update(fos_fista* f);
  * cheap way to read ||grad|| for the gradient-norm stop (:179). */
 int fos_fista_trial(fos_fista* f, double t, int with_residual, double out8[8]);
 /* The same test for nv <= 16 candidate steps t, t*eta, t*eta^2, ... decided by ONE pass over A on the matrix
- * cores (v_mfma_f32_16x16x4_f32, LDS-staged A tiles; the candidates are the N dimension).  out (host) = nv rows of
+ * cores (v_mfma_f32_16x16x4_f32, or v_mfma_f32_16x16x32_bf16 on three-term bf16 candidates when A is bf16;
+ * LDS-staged A tiles; the candidates are the N dimension).  out (host) = nv rows of
  * 8 doubles, each laid out like out8 of fos_fista_trial.  Synchronises.  FOS_ERR_UNSUPPORTED when the problem runs
  * the two-pass fallback (ragged shapes): callers then loop over fos_fista_trial.  SURVEY.md 8(f) rank 1. */
 int fos_fista_trial_batch(fos_fista* f, double t, double eta, int nv, double* out);

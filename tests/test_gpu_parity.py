@@ -477,6 +477,53 @@ def test_residual_batch_mfma_vs_oracle(fos, m, n, nv):
         assert np.allclose(got, want, rtol=TOL), (use_b, got, want)
 
 
+@pytest.mark.parametrize("m,n,nv", [(64, 16, 16), (1000, 512, 5), (777, 136, 3), (4099, 8192, 16), (130, 16384, 9), (1, 8, 1),
+                                    (32845, 264, 7)])          # the last one is tall enough for the 128-row tile
+def test_residual_batch_mfma_bf16_vs_oracle(fos, m, n, nv):
+    """bf16 A on v_mfma_f32_16x16x32_bf16: the candidates are split into three bf16 terms (24 mantissa bits), so the
+    result keeps the fp32 tolerance against the float64 product with the bf16-ROUNDED A."""
+    rng = np.random.default_rng(m + n + nv)
+    A16 = torch.as_tensor(rng.standard_normal((m, n)).astype(np.float32)).to(torch.bfloat16)
+    Aq = A16.to(torch.float64).numpy()
+    b = rng.standard_normal(m).astype(np.float32)
+    X = (rng.standard_normal((n, nv)) * np.logspace(0, -6, nv)).astype(np.float32)
+    prob = fos.prepare(A16.cuda(), b)
+    assert prob.plan()["path"] == 0 and prob.dtype == "bf16"
+    for use_b in (True, False):
+        got = prob.residual_batch(X, use_b=use_b)
+        R = Aq @ X.astype(np.float64) - (b.astype(np.float64)[:, None] if use_b else 0.0)
+        assert np.allclose(got, (R ** 2).sum(axis=0), rtol=TOL), (use_b, got)
+
+
+def test_bf16_backtracking_uses_mfma_batch_and_matches_oracle(fos):
+    """Backtracking FISTA with bf16 A: the batched (bf16 MFMA) search takes the decisions of the sequential one and
+    the iterates follow the oracle run on the bf16-rounded A."""
+    from fastoptsolver_amd import iterative_solvers as its
+    rng = np.random.default_rng(33)
+    m, n = 2000, 1024
+    A16 = torch.as_tensor(rng.standard_normal((m, n)).astype(np.float32)).to(torch.bfloat16)
+    Aq = A16.to(torch.float64).numpy()
+    b = Aq @ (rng.standard_normal(n) * (rng.random(n) < 0.05)) + 0.1 * rng.standard_normal(m)
+    lam = float(np.max(np.abs(Aq.T @ b)))
+    L = float(np.linalg.norm(Aq, 2) ** 2)
+    prob = fos.prepare(A16.cuda(), b)
+    tf, iters = 8.0, 18      # a generous first step: 2, 1, 0, 0, 0, 4, 2, 9 ... shrinks; the reference's first
+    out = {}                 # step-underflow event (see _check_linesearch_counts) comes at iteration 19 on this data
+    for batch in (True, False):
+        its.reset_metrics()
+        st = its._drive(prob, A16, mode=0, prox_kind=0, alpha1=0.05 * lam, alpha2=0.5, tau=tf / (L + 0.5),
+                        backtracking=True, eta=0.7, max_iter=iters, batch_trials=batch)
+        out[batch] = (st.x_tensor().cpu().numpy(), list(its.ls_call_iters))
+    assert out[True][1] == out[False][1] and sum(out[True][1]) > 0
+    assert _data.rel(out[True][0], out[False][0]) < 1e-9
+    ref = orc.FistaProblem(Aq, b, 0.05 * lam, 0.5)
+    rs = ref.init_state(L, tf)
+    for _ in range(iters):
+        ref.step(rs, backtracking=True, eta=0.7)
+    assert _data.rel(out[True][0], rs.x) < TOL
+    assert max(ref.metrics.ls_iters) < 40 and out[True][1] == ref.metrics.ls_iters
+
+
 def test_batched_and_sequential_line_search_agree(fos):
     """The MFMA-batched Armijo search must take exactly the decisions of the one-candidate-per-pass search."""
     from fastoptsolver_amd import iterative_solvers as its

@@ -9,10 +9,13 @@ from fastoptsolver_amd import iterative_solvers as its
 from bench import make_shard, WORKLOADS
 
 torch.cuda.set_device(0)
-cfg = WORKLOADS["cfg2"]
+DT = "bf16" if "--dtype=bf16" in sys.argv else "f32"          # bf16: A stored in bf16, 3-term bf16 MFMA batch kernel
+cfg = dict(WORKLOADS["cfg2"])
 A, b = make_shard(cfg, 0, cfg["m"], torch.device("cuda", 0))
+if DT == "bf16":
+    A = A.to(torch.bfloat16)
 prob = fos.prepare(A, b)
-lam = float((A.T @ b).abs().max())
+lam = float((A.float().T @ b).abs().max())
 np.random.seed(0)
 L = fos.estimate_lipschitz(prob)
 out = {}
@@ -36,8 +39,8 @@ for _ in range(20):
     prob.residual_batch(X)
 ms, cnt = prob.profile_read()
 us = ms * 1e3 / cnt
-byts = cfg["m"] * cfg["n"] * 4
+byts = cfg["m"] * cfg["n"] * (2 if DT == "bf16" else 4)
 out["residual_batch_mfma_kernel"] = dict(us=us, gbps=byts / (us * 1e-6) / 1e9, frac_hbm=byts / (us * 1e-6) / 8e12,
-                                         tflops=2.0 * cfg["m"] * cfg["n"] * 16 / (us * 1e-6) / 1e12)
+                                         tflops=2.0 * cfg["m"] * cfg["n"] * 16 * (3 if DT == "bf16" else 1) / (us * 1e-6) / 1e12)
 print(out["residual_batch_mfma_kernel"], flush=True)
-json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "bench_linesearch.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", f"bench_linesearch_{DT}.json"), "w"), indent=1)
