@@ -104,17 +104,20 @@ __global__ __launch_bounds__(256) void fista_trial_batch_kernel(const float* __r
 
 // q_part[wg][j] = sum over this workgroup's rows of (A_i . X_j - use_b * b_i)^2.
 // Requirements (host-checked): n % 4 == 0, lda % 4 == 0, A 16-byte aligned, Xp zero-padded to n_pad = 64*ceil(n/64).
-__global__ __launch_bounds__(BT_THREADS, 2) void residual_batch_mfma_kernel(const float* __restrict__ A, int64_t lda,
-                                                                           const float* __restrict__ b, int use_b,
-                                                                           int64_t m, int n,
-                                                                           const float* __restrict__ xp,
-                                                                           int64_t groups_per_wg,
-                                                                           double* __restrict__ q_part) {
-  __shared__ __attribute__((aligned(16))) float a_s[2][BT_ROWS][BT_LDS_STRIDE];
+template <int RB>
+__global__ __launch_bounds__(BT_THREADS) void residual_batch_mfma_kernel(const float* __restrict__ A, int64_t lda,
+                                                                        const float* __restrict__ b, int use_b,
+                                                                        int64_t m, int n,
+                                                                        const float* __restrict__ xp,
+                                                                        int64_t groups_per_wg,
+                                                                        double* __restrict__ q_part) {
+  constexpr int ROWS = BT_ROWS * RB;              // RB 16-row blocks per wave share each candidate fragment read
+  constexpr int A_LOADS = BT_A_LOADS * RB;
+  __shared__ __attribute__((aligned(16))) float a_s[2][ROWS][BT_LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) float x_s[2][BT_COLS * BT_NV];
   __shared__ double wsum[4][BT_NV];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t ngroups = (m + BT_ROWS - 1) / BT_ROWS;
+  const int64_t ngroups = (m + ROWS - 1) / ROWS;
   const int64_t g_lo = (int64_t)blockIdx.x * groups_per_wg;
   int64_t g_hi = g_lo + groups_per_wg;
   if (g_hi > ngroups) g_hi = ngroups;
@@ -123,15 +126,15 @@ __global__ __launch_bounds__(BT_THREADS, 2) void residual_batch_mfma_kernel(cons
 
   // Two register sets: the loads of tile t+2 are issued while tile t is on the matrix cores and tile t+1 waits in
   // registers for its turn in LDS -> two 16 KiB tiles in flight per workgroup (x 3 workgroups per CU).
-  f32x4 areg[2][BT_A_LOADS];
+  f32x4 areg[2][A_LOADS];
   f32x4 xreg[2][BT_X_LOADS];
   auto load_tile = [&](int set, int64_t t) {
     const int64_t grp = g_lo + t / ktiles;
     const int kt = (int)(t % ktiles);
-    const int64_t row0 = grp * BT_ROWS;
+    const int64_t row0 = grp * ROWS;
     const int col0 = kt * BT_COLS;
 #pragma unroll
-    for (int u = 0; u < BT_A_LOADS; ++u) {
+    for (int u = 0; u < A_LOADS; ++u) {
       const int f = u * BT_THREADS + tid;
       int64_t row = row0 + f / BT_F4_ROW;
       int col = col0 + 4 * (f % BT_F4_ROW);
@@ -145,46 +148,54 @@ __global__ __launch_bounds__(BT_THREADS, 2) void residual_batch_mfma_kernel(cons
   };
   auto store_tile = [&](int set, int buf) {
 #pragma unroll
-    for (int u = 0; u < BT_A_LOADS; ++u) {
+    for (int u = 0; u < A_LOADS; ++u) {
       const int f = u * BT_THREADS + tid;
       *reinterpret_cast<f32x4*>(&a_s[buf][f / BT_F4_ROW][4 * (f % BT_F4_ROW)]) = areg[set][u];
     }
 #pragma unroll
     for (int u = 0; u < BT_X_LOADS; ++u) *reinterpret_cast<f32x4*>(&x_s[buf][4 * (u * BT_THREADS + tid)]) = xreg[set][u];
   };
-  // two accumulators (even / odd MFMA steps): v_mfma_f32_16x16x4_f32 issues every 32 cycles but a dependent one
-  // needs 40 - one chain would leave the pipe idle a fifth of the time (profiles: 27 % issue stall with one chain)
-  f32x4 acc_odd = {0.f, 0.f, 0.f, 0.f};
-  auto compute_tile = [&](int buf, int64_t t, f32x4& acc, double& qsum) {
+  // two accumulators per row block (even / odd MFMA steps): v_mfma_f32_16x16x4_f32 issues every 32 cycles but a
+  // dependent one needs 40 - one chain would leave the pipe idle a fifth of the time
+  f32x4 acc[RB], acc_odd[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) { acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_odd[rb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  double qsum = 0.0;                              // this lane's candidate j = lane & 15, its 4 rows per row block
+  auto compute_tile = [&](int buf, int64_t t) {
 #pragma unroll
     for (int sub = 0; sub < BT_COLS / 16; ++sub) {
-      const f32x4 a4 = *reinterpret_cast<const f32x4*>(&a_s[buf][16 * wave + (lane & 15)][16 * sub + 4 * (lane >> 4)]);
       const f32x4 x4 = *reinterpret_cast<const f32x4*>(&x_s[buf][(sub * 4 + (lane >> 4)) * 64 + (lane & 15) * 4]);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, x4.x, acc, 0, 0, 0);
-      acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, x4.y, acc_odd, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, x4.z, acc, 0, 0, 0);
-      acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, x4.w, acc_odd, 0, 0, 0);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const f32x4 a4 =
+            *reinterpret_cast<const f32x4*>(&a_s[buf][16 * (wave * RB + rb) + (lane & 15)][16 * sub + 4 * (lane >> 4)]);
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, x4.x, acc[rb], 0, 0, 0);
+        acc_odd[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, x4.y, acc_odd[rb], 0, 0, 0);
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, x4.z, acc[rb], 0, 0, 0);
+        acc_odd[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, x4.w, acc_odd[rb], 0, 0, 0);
+      }
     }
     if ((t + 1) % ktiles == 0) {
-      acc += acc_odd;
-      acc_odd = f32x4{0.f, 0.f, 0.f, 0.f};
       // row group complete: D[row = 4*(lane>>4)+reg][candidate = lane&15]
-      const int64_t row0 = (g_lo + t / ktiles) * BT_ROWS + 16 * wave + 4 * (lane >> 4);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t row = row0 + r;
-        if (row < m) {
-          float v = acc[r];
-          if (use_b) v -= b[row];
-          qsum += (double)v * (double)v;
+      for (int rb = 0; rb < RB; ++rb) {
+        acc[rb] += acc_odd[rb];
+        const int64_t row0 = (g_lo + t / ktiles) * ROWS + 16 * (wave * RB + rb) + 4 * (lane >> 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = row0 + r;
+          if (row < m) {
+            float v = acc[rb][r];
+            if (use_b) v -= b[row];
+            qsum += (double)v * (double)v;
+          }
         }
+        acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc_odd[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      acc = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
 
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  double qsum = 0.0;                              // this lane's candidate j = lane & 15, its 4 rows
   // Straight-line pair loop: loads and LDS stores are unconditional (tile index clamped to the last tile: redundant
   // L2 hits at the tail), so the compiler can wait for a register set with a COUNTED vmcnt and leave the set it has
   // just issued in flight.  A conditional load_tile / store_tile forces vmcnt(0) (DESIGN.md "What the ISA showed").
@@ -199,16 +210,16 @@ __global__ __launch_bounds__(BT_THREADS, 2) void residual_batch_mfma_kernel(cons
     for (; t + 2 <= ntiles; t += 2) {
       // even step: tile t in LDS buffer 0, tile t+1 in register set 1
       load_tile(0, clampt(t + 2));
-      compute_tile(0, t, acc, qsum);
+      compute_tile(0, t);
       store_tile(1, 1);
       __syncthreads();
       // odd step: tile t+1 in LDS buffer 1, tile t+2 in register set 0
       load_tile(1, clampt(t + 3));
-      compute_tile(1, t + 1, acc, qsum);
+      compute_tile(1, t + 1);
       store_tile(0, 0);
       __syncthreads();
     }
-    if (t < ntiles) compute_tile(0, t, acc, qsum);   // odd count: the last tile sits in buffer 0
+    if (t < ntiles) compute_tile(0, t);   // odd count: the last tile sits in buffer 0
   }
   // lanes j, j+16, j+32, j+48 hold candidate j
   qsum += __shfl_xor(qsum, 16, 64);

@@ -461,7 +461,8 @@ def test_ista_with_arbitrary_torch_closures(fos):
         assert _data.rel(x, fx[key + "/x"]) < TOL, key
 
 
-@pytest.mark.parametrize("m,n,nv", [(64, 16, 16), (1000, 512, 5), (777, 132, 3), (4099, 8192, 16), (130, 16384, 9), (1, 4, 1)])
+@pytest.mark.parametrize("m,n,nv", [(64, 16, 16), (1000, 512, 5), (777, 132, 3), (4099, 8192, 16), (130, 16384, 9), (1, 4, 1),
+                                    (32845, 260, 7)])          # the last one is tall enough for the 128-row tile
 def test_residual_batch_mfma_vs_oracle(fos, m, n, nv):
     """The batched (matrix-core) residual kernel: ||A X_j - b||^2 for up to 16 vectors in one pass."""
     rng = np.random.default_rng(m + n + nv)
