@@ -1135,18 +1135,18 @@ int fos_lbfgs_two_loop(const float* g, const float* S, const float* Y, int hist,
   return FOS_OK;
 }
 
-int fos_vec_stats(const float* x, const float* g, const float* d, int64_t n, double* out4, void* stream) {
-  if (!out4 || n <= 0) return fail(FOS_ERR_ARG, "fos_vec_stats: bad argument");
+int fos_vec_stats(const float* x, const float* g, const float* d, int64_t n, double* out5, void* stream) {
+  if (!out5 || n <= 0) return fail(FOS_ERR_ARG, "fos_vec_stats: bad argument");
   hipLaunchKernelGGL(fos::vec_stats_kernel<float>, dim3(1), dim3(fos::LB_THREADS), 0, (hipStream_t)stream, x, g, d, n,
-                     out4);
+                     out5);
   LAUNCH_CHECK();
   return FOS_OK;
 }
 
-int fos_vec_stats_f64(const double* x, const float* g, const float* d, int64_t n, double* out4, void* stream) {
-  if (!out4 || n <= 0) return fail(FOS_ERR_ARG, "fos_vec_stats_f64: bad argument");
+int fos_vec_stats_f64(const double* x, const float* g, const float* d, int64_t n, double* out5, void* stream) {
+  if (!out5 || n <= 0) return fail(FOS_ERR_ARG, "fos_vec_stats_f64: bad argument");
   hipLaunchKernelGGL(fos::vec_stats_kernel<double>, dim3(1), dim3(fos::LB_THREADS), 0, (hipStream_t)stream, x, g, d, n,
-                     out4);
+                     out5);
   LAUNCH_CHECK();
   return FOS_OK;
 }

@@ -162,30 +162,32 @@ __global__ __launch_bounds__(LB_THREADS) void lbfgs_two_loop_kernel(const float*
   }
 }
 
-// out4 = { x.x, g.d, d.d, max|g| }; any pointer may be NULL (its entries are then 0).  XT: float or double iterate.
+// out5 = { x.x, g.d, d.d, max|g|, ||x||_1 }; any pointer may be NULL (its entries are then 0).  XT: float or double
+// iterate.
 template <typename XT>
 __global__ __launch_bounds__(LB_THREADS) void vec_stats_kernel(const XT* __restrict__ x, const float* __restrict__ g,
                                                                const float* __restrict__ d, int64_t n,
-                                                               double* __restrict__ out4) {
-  __shared__ double lds[4][16];
-  double xx = 0.0, gd = 0.0, dd = 0.0, gm = 0.0;
+                                                               double* __restrict__ out5) {
+  __shared__ double lds[5][16];
+  double xx = 0.0, gd = 0.0, dd = 0.0, gm = 0.0, x1 = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += LB_THREADS) {
     const double xv = x ? (double)x[i] : 0.0, gv = g ? (double)g[i] : 0.0, dv = d ? (double)d[i] : 0.0;
     xx += xv * xv;
+    x1 += fabs(xv);
     gd += gv * dv;
     dd += dv * dv;
     gm = fmax(gm, fabs(gv));
   }
-  xx = wave_sum(xx); gd = wave_sum(gd); dd = wave_sum(dd);
+  xx = wave_sum(xx); gd = wave_sum(gd); dd = wave_sum(dd); x1 = wave_sum(x1);
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) gm = fmax(gm, __shfl_xor(gm, off, 64));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { lds[0][wave] = xx; lds[1][wave] = gd; lds[2][wave] = dd; lds[3][wave] = gm; }
+  if (lane == 0) { lds[0][wave] = xx; lds[1][wave] = gd; lds[2][wave] = dd; lds[3][wave] = gm; lds[4][wave] = x1; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double a = 0.0, b = 0.0, c = 0.0, e = 0.0;
-    for (int i = 0; i < 16; ++i) { a += lds[0][i]; b += lds[1][i]; c += lds[2][i]; e = fmax(e, lds[3][i]); }
-    out4[0] = a; out4[1] = b; out4[2] = c; out4[3] = e;
+    double a = 0.0, b = 0.0, c = 0.0, e = 0.0, f = 0.0;
+    for (int i = 0; i < 16; ++i) { a += lds[0][i]; b += lds[1][i]; c += lds[2][i]; e = fmax(e, lds[3][i]); f += lds[4][i]; }
+    out5[0] = a; out5[1] = b; out5[2] = c; out5[3] = e; out5[4] = f;
   }
 }
 

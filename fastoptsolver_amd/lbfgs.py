@@ -17,7 +17,6 @@ import torch
 from . import _core, _lib
 from ._linesearch import LineSearch
 from .iterative_solvers import _EventTimer, grad_call_times, reset_metrics
-from .objective_functions import compute_objective
 from .operators import vec_axpby
 
 _M, _FACTR, _MAXLS = 10, 1e7, 20
@@ -58,9 +57,10 @@ class LBFGSSolver:
         a2 = float(self.alpha2) if self.reg_type in ("ridge", "elasticnet") else 0.0   # lbfgs.py:49-51
         gtimer = _EventTimer(grad_call_times)
         stats = torch.zeros(8, dtype=torch.float64, device=dev)
-        rr_dev = stats[4:5]
+        rr_dev = stats[5:6]
         self.nfev_ = 0
         self.iterates_ = []
+        device_iterates = []                      # fp64 device vectors; copied to the host once, after the run
 
         def fg(x, d):
             """loss, grad (device), and the scalars g.d, d.d, max|g| in one host read.   lbfgs.py:43-54
@@ -74,9 +74,10 @@ class LBFGSSolver:
             with torch.cuda.device(dev):
                 _lib.check(lib.fos_vec_stats_f64(_core.ptr(x), _core.ptr(g), _core.ptr(d), n, _core.ptr(stats),
                                                  _core.stream_ptr()), "fos_vec_stats_f64")
-            h = stats[:5].cpu().tolist()
+            h = stats[:6].cpu().tolist()
             self.nfev_ += 1
-            loss = 0.5 * h[4] + 0.5 * a2 * h[0]
+            loss = 0.5 * h[5] + 0.5 * a2 * h[0]
+            self._x1 = h[4]                       # ||x||_1 of the point just evaluated (for the history objective)
             return loss, g, h[1], h[2], h[3]
 
         def direction(g, S, Y, hist, head):
@@ -86,9 +87,13 @@ class LBFGSSolver:
                                                   _core.ptr(d), _core.stream_ptr()), "fos_lbfgs_two_loop")
             return d
 
-        def callback(xk):                                                           # lbfgs.py:56-61
-            self.iterates_.append(_core.from_device_vec(prob.vec_out(xk), like))
-            self.history_.append(compute_objective(xk, prob, None, self.reg_type, self.alpha1, self.alpha2))
+        def callback(xk, f_xk):                                                     # lbfgs.py:56-61
+            # compute_objective(xk) = smooth loss + alpha1*||xk||_1 (objective_functions.py:13-26).  The line search
+            # ends on the point it evaluated last, so fg's loss and ||x||_1 ARE those of xk: no extra pass over A
+            # (the reference pays one per iteration here).
+            device_iterates.append(xk)
+            h = self.alpha1 * self._x1 if self.reg_type in ("lasso", "elasticnet") else 0.0
+            self.history_.append(f_xk + h)
 
         def step_to(x_old, stp, d):
             out = torch.empty(n, dtype=torch.float64, device=dev)
@@ -141,7 +146,7 @@ class LBFGSSolver:
             if flat >= _FLAT_TRIALS and ls.status == "FG":
                 if f <= f_old:
                     nit += 1
-                    callback(x)
+                    callback(x, f)
                 else:
                     x, g, f = x_old, g_old, f_old
                 task = "CONVERGENCE: LINE SEARCH REACHED THE FLOAT32 RESOLUTION OF F"
@@ -155,7 +160,7 @@ class LBFGSSolver:
                 continue
             stp = stp_used
             nit += 1
-            callback(x)
+            callback(x, f)
             if nit >= self.max_iter:
                 task = "STOP: TOTAL NO. OF ITERATIONS REACHED LIMIT"
                 break
@@ -175,6 +180,7 @@ class LBFGSSolver:
                 vec_axpby(stp, d, 0.0, None, out=S[slot])
                 vec_axpby(1.0, g, -1.0, g_old, out=Y[slot])
         gtimer.flush()
+        self.iterates_ = [_core.from_device_vec(prob.vec_out(xk), like) for xk in device_iterates]
         self.x_ = _core.from_device_vec(prob.vec_out(x), like)                        # lbfgs.py:71
         self.final_obj_ = f                                                           # lbfgs.py:72
         self.nit_, self.task_ = nit, task

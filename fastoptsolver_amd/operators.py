@@ -17,10 +17,11 @@ def vec_axpby(a, x, b, y, out=None):
 
 
 def vec_stats(x, g, d):
-    """Host list [x.x, g.d, d.d, max|g|] in one launch (fos_vec_stats); any argument may be None.  Synchronises."""
+    """Host list [x.x, g.d, d.d, max|g|, ||x||_1] in one launch (fos_vec_stats); any argument may be None.
+    Synchronises."""
     lib = _lib.load()
     ref = next(t for t in (x, g, d) if t is not None)
-    out = torch.empty(4, dtype=torch.float64, device=ref.device)
+    out = torch.empty(5, dtype=torch.float64, device=ref.device)
     with torch.cuda.device(ref.device):
         _lib.check(lib.fos_vec_stats(_core.ptr(x), _core.ptr(g), _core.ptr(d), ref.numel(), _core.ptr(out),
                                      _core.stream_ptr()), "fos_vec_stats")

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FOS_ABI_VERSION 1
+#define FOS_ABI_VERSION 2
 
 enum { FOS_OK = 0, FOS_ERR_ARG = -1, FOS_ERR_HIP = -2, FOS_ERR_STATE = -3, FOS_ERR_UNSUPPORTED = -4 };
 enum { FOS_F32 = 0, FOS_BF16 = 1 };                    /* element type of A */
@@ -173,12 +173,12 @@ float* fos_fista_gbuf(fos_fista* f);     /* device pointer to gbuf (n+1 floats),
  * slot (head + i) % cap holds the i-th oldest pair.  One launch. */
 int fos_lbfgs_two_loop(const float* g, const float* S, const float* Y, int hist, int head, int cap, int64_t n,
                        float* d_out, void* stream);
-/* out4 (device doubles) = { x.x, g.d, d.d, max|g| } in one launch. */
-int fos_vec_stats(const float* x, const float* g, const float* d, int64_t n, double* out4, void* stream);
+/* out5 (device doubles) = { x.x, g.d, d.d, max|g|, ||x||_1 } in one launch; x, g, d may each be NULL. */
+int fos_vec_stats(const float* x, const float* g, const float* d, int64_t n, double* out5, void* stream);
 /* out = a*x + b*y (y may be NULL when b == 0). */
 int fos_vec_axpby(double a, const float* x, double b, const float* y, float* out, int64_t n, void* stream);
 /* fp64-iterate forms: x and out in fp64, g / d / y in fp32. */
-int fos_vec_stats_f64(const double* x, const float* g, const float* d, int64_t n, double* out4, void* stream);
+int fos_vec_stats_f64(const double* x, const float* g, const float* d, int64_t n, double* out5, void* stream);
 int fos_vec_axpby_f64(double a, const double* x, double b, const float* y, double* out, int64_t n, void* stream);
 
 #ifdef __cplusplus

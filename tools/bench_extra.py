@@ -38,6 +38,7 @@ def main():
     cfg = WORKLOADS["cfg2"]
     A, b = make_shard(cfg, 0, cfg["m"], dev)
     prob = fos.prepare(A, b)
+    fos.LBFGSSolver("ridge", 0.0, 1.0).fit(prob, None)          # warm-up (first launches, workspace allocation)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     s = fos.LBFGSSolver("ridge", 0.0, 1.0).fit(prob, None)
