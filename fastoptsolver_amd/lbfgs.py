@@ -13,6 +13,7 @@ convergence, exactly as L-BFGS-B treats its own ABNORMAL_TERMINATION_IN_LNSRCH.
 """
 import numpy as np
 import torch
+import torch.distributed as dist
 
 from . import _core, _lib
 from ._linesearch import LineSearch
@@ -23,6 +24,70 @@ _M, _FACTR, _MAXLS = 10, 1e7, 20
 _EPS = float(np.finfo(np.float64).eps)
 _EPS32 = float(np.finfo(np.float32).eps)
 _FLAT_TRIALS = 3     # consecutive trial points whose objective is indistinguishable from f(x_k) in float32
+
+
+class _HipOps:
+    """The device primitives of one fit: K2 pass, two-loop K4, n-vector kernels.  No CPU fallback."""
+
+    def __init__(self, A, b):
+        self.lib = _lib.load()
+        self.prob = _core.as_problem(A, b)
+        self.n, self.dev = self.prob.n_dev, self.prob.device   # device length (zero-padded columns stay exactly zero)
+        self._stats = torch.zeros(8, dtype=torch.float64, device=self.dev)
+        self.rr = self._stats[5:6]
+
+    def timer(self, sink):
+        return _EventTimer(sink)
+
+    def comm_buffer(self):
+        return torch.zeros(self.n + 1, dtype=torch.float64, device=self.dev)
+
+    def new_x(self):
+        return torch.zeros(self.n, dtype=torch.float64, device=self.dev)
+
+    def new_g(self):
+        return torch.empty(self.n, dtype=torch.float32, device=self.dev)
+
+    def new_history(self, cap):
+        return (torch.zeros(cap, self.n, dtype=torch.float32, device=self.dev),
+                torch.zeros(cap, self.n, dtype=torch.float32, device=self.dev))
+
+    def grad(self, x, a2, g):
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.fos_gemv_pair_f64(self.prob.h, _core.ptr(x), a2, _core.ptr(g), _core.ptr(self.rr)),
+                       "fos_gemv_pair_f64")
+
+    def stats(self, x, g, d):
+        """Host list [x.x, g.d, d.d, max|g|, ||x||_1, ||r||^2 of the last grad()]: one launch, one read."""
+        with torch.cuda.device(self.dev):
+            if x is None:
+                _lib.check(self.lib.fos_vec_stats(None, _core.ptr(g), _core.ptr(d), self.n, _core.ptr(self._stats),
+                                                  _core.stream_ptr()), "fos_vec_stats")
+            else:
+                _lib.check(self.lib.fos_vec_stats_f64(_core.ptr(x), _core.ptr(g), _core.ptr(d), self.n,
+                                                      _core.ptr(self._stats), _core.stream_ptr()), "fos_vec_stats_f64")
+        return self._stats[:6].cpu().tolist()
+
+    def direction(self, g, S, Y, hist, head):
+        d = torch.empty(self.n, dtype=torch.float32, device=self.dev)
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.fos_lbfgs_two_loop(_core.ptr(g), _core.ptr(S), _core.ptr(Y), hist, head, _M, self.n,
+                                                   _core.ptr(d), _core.stream_ptr()), "fos_lbfgs_two_loop")
+        return d
+
+    def step_to(self, x_old, stp, d):
+        out = torch.empty(self.n, dtype=torch.float64, device=self.dev)
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.fos_vec_axpby_f64(1.0, _core.ptr(x_old), float(stp), _core.ptr(d), _core.ptr(out),
+                                                  self.n, _core.stream_ptr()), "fos_vec_axpby_f64")
+        return out
+
+    def store_pair(self, S, Y, slot, stp, d, g, g_old):
+        vec_axpby(stp, d, 0.0, None, out=S[slot])
+        vec_axpby(1.0, g, -1.0, g_old, out=Y[slot])
+
+    def to_caller(self, x):
+        return _core.from_device_vec(self.prob.vec_out(x), self.prob.like)
 
 
 class LBFGSSolver:
@@ -48,16 +113,19 @@ class LBFGSSolver:
         self.history_ = []
 
     # ------------------------------------------------------------------------------------------------------
-    def fit(self, A, b):
+    def fit(self, A, b, *, group=None, ops=None):
+        """``group``: a torch.distributed process group -> A, b are THIS RANK's rows of a row-sharded problem; every
+        ``fg`` all-reduces [partial gradient ; partial ||r||^2] once and all ranks take identical
+        decisions on identical numbers, so x stays replicated bit for bit.  ``ops``: the vector/pass primitives
+        (default: the HIP kernels; the gloo CPU test injects a stand-in)."""
         reset_metrics()
-        lib = _lib.load()
-        prob = _core.as_problem(A, b)
-        like = prob.like
-        n, dev = prob.n_dev, prob.device          # device length (zero-padded columns stay exactly zero)
+        ops = ops if ops is not None else _HipOps(A, b)
+        sharded = group is not None and dist.get_world_size(group) > 1
         a2 = float(self.alpha2) if self.reg_type in ("ridge", "elasticnet") else 0.0   # lbfgs.py:49-51
-        gtimer = _EventTimer(grad_call_times)
-        stats = torch.zeros(8, dtype=torch.float64, device=dev)
-        rr_dev = stats[5:6]
+        # alpha2*x enters the summed gradient exactly once: rank 0 adds it inside its pass, the others do not
+        a2_pass = a2 if (not sharded or dist.get_rank(group) == 0) else 0.0
+        gtimer = ops.timer(grad_call_times)
+        comm = ops.comm_buffer() if sharded else None
         self.nfev_ = 0
         self.iterates_ = []
         device_iterates = []                      # fp64 device vectors; copied to the host once, after the run
@@ -66,26 +134,23 @@ class LBFGSSolver:
             """loss, grad (device), and the scalars g.d, d.d, max|g| in one host read.   lbfgs.py:43-54
             x is the fp64 iterate; the pass over A sees it rounded once to fp32 (kept in fp64 on the two-pass path)."""
             ev = gtimer.start()
-            g = torch.empty(n, dtype=torch.float32, device=dev)
-            with torch.cuda.device(dev):
-                _lib.check(lib.fos_gemv_pair_f64(prob.h, _core.ptr(x), a2, _core.ptr(g), _core.ptr(rr_dev)),
-                           "fos_gemv_pair_f64")
+            g = ops.new_g()
+            ops.grad(x, a2_pass, g)                               # g = A_p^T (A_p x - b_p) [+ a2 x], ops.rr = ||r_p||^2
+            if sharded:
+                n_ = g.numel()
+                comm[:n_].copy_(g)
+                comm[n_:].copy_(ops.rr)
+                dist.all_reduce(comm, op=dist.ReduceOp.SUM, group=group)
+                g.copy_(comm[:n_])
+                ops.rr.copy_(comm[n_:])
             gtimer.stop(ev)
-            with torch.cuda.device(dev):
-                _lib.check(lib.fos_vec_stats_f64(_core.ptr(x), _core.ptr(g), _core.ptr(d), n, _core.ptr(stats),
-                                                 _core.stream_ptr()), "fos_vec_stats_f64")
-            h = stats[:6].cpu().tolist()
+            h = ops.stats(x, g, d)                                # [x.x, g.d, d.d, max|g|, ||x||_1, ||r||^2]
             self.nfev_ += 1
             loss = 0.5 * h[5] + 0.5 * a2 * h[0]
             self._x1 = h[4]                       # ||x||_1 of the point just evaluated (for the history objective)
             return loss, g, h[1], h[2], h[3]
 
-        def direction(g, S, Y, hist, head):
-            d = torch.empty(n, dtype=torch.float32, device=dev)
-            with torch.cuda.device(dev):
-                _lib.check(lib.fos_lbfgs_two_loop(_core.ptr(g), _core.ptr(S), _core.ptr(Y), hist, head, _M, n,
-                                                  _core.ptr(d), _core.stream_ptr()), "fos_lbfgs_two_loop")
-            return d
+        direction, step_to = ops.direction, ops.step_to
 
         def callback(xk, f_xk):                                                     # lbfgs.py:56-61
             # compute_objective(xk) = smooth loss + alpha1*||xk||_1 (objective_functions.py:13-26).  The line search
@@ -95,16 +160,8 @@ class LBFGSSolver:
             h = self.alpha1 * self._x1 if self.reg_type in ("lasso", "elasticnet") else 0.0
             self.history_.append(f_xk + h)
 
-        def step_to(x_old, stp, d):
-            out = torch.empty(n, dtype=torch.float64, device=dev)
-            with torch.cuda.device(dev):
-                _lib.check(lib.fos_vec_axpby_f64(1.0, _core.ptr(x_old), float(stp), _core.ptr(d), _core.ptr(out), n,
-                                                 _core.stream_ptr()), "fos_vec_axpby_f64")
-            return out
-
-        x = torch.zeros(n, dtype=torch.float64, device=dev)                          # lbfgs.py:63 (fp64 iterate)
-        S = torch.zeros(_M, n, dtype=torch.float32, device=dev)
-        Y = torch.zeros(_M, n, dtype=torch.float32, device=dev)
+        x = ops.new_x()                                                              # lbfgs.py:63 (fp64 iterate)
+        S, Y = ops.new_history(_M)
         hist, head = 0, 0
         f, g, _, _, gmax = fg(x, None)
         nit, task = 0, None
@@ -112,10 +169,7 @@ class LBFGSSolver:
             task = "CONVERGENCE: NORM_OF_PROJECTED_GRADIENT_<=_PGTOL"
         while task is None:
             d = direction(g, S, Y, hist, head)
-            with torch.cuda.device(dev):
-                _lib.check(lib.fos_vec_stats(None, _core.ptr(g), _core.ptr(d), n, _core.ptr(stats),
-                                             _core.stream_ptr()), "fos_vec_stats")
-            _, gd0, dd, _ = stats[:4].cpu().tolist()
+            _, gd0, dd = ops.stats(None, g, d)[:3]
             if gd0 >= 0.0:                       # not a descent direction: drop the memory (L-BFGS-B info = -4)
                 if hist == 0:
                     task = "ABNORMAL_TERMINATION_IN_LNSRCH"
@@ -177,11 +231,10 @@ class LBFGSSolver:
                     head = (head + 1) % _M
                 else:
                     hist += 1
-                vec_axpby(stp, d, 0.0, None, out=S[slot])
-                vec_axpby(1.0, g, -1.0, g_old, out=Y[slot])
+                ops.store_pair(S, Y, slot, stp, d, g, g_old)
         gtimer.flush()
-        self.iterates_ = [_core.from_device_vec(prob.vec_out(xk), like) for xk in device_iterates]
-        self.x_ = _core.from_device_vec(prob.vec_out(x), like)                        # lbfgs.py:71
+        self.iterates_ = [ops.to_caller(xk) for xk in device_iterates]
+        self.x_ = ops.to_caller(x)                                                    # lbfgs.py:71
         self.final_obj_ = f                                                           # lbfgs.py:72
         self.nit_, self.task_ = nit, task
         return self
