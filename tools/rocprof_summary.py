@@ -21,6 +21,7 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DOMINANT = "fos::gemv_pair_kernel"
+DOMINANT_EXTRA = ""
 
 
 def find(d, pattern):
@@ -53,8 +54,12 @@ def main():
     ap.add_argument("--kernel-trace", required=True)
     ap.add_argument("--fetch", required=True)
     ap.add_argument("--write", required=True)
-    ap.add_argument("--command", default="python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-scale-ref")
+    ap.add_argument("--command", default="python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline")
+    ap.add_argument("--match", default="", help="extra substring the dominant kernel's name must contain "
+                                                 "(e.g. 'float, 512' to pick one geometry when a run holds several)")
     a = ap.parse_args()
+    global DOMINANT_EXTRA
+    DOMINANT_EXTRA = a.match
     out_dir = os.path.join(ROOT, "profiles")
     os.makedirs(out_dir, exist_ok=True)
 
@@ -65,7 +70,7 @@ def main():
     dom = None
     for r in rows:
         name = r["Name"]
-        if DOMINANT in name and dom is None:
+        if DOMINANT in name and DOMINANT_EXTRA in name and dom is None:
             dom = r
         short = name.split("(")[0].replace("void ", "")[:90]
         lines.append(f"| `{short}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | "
@@ -95,7 +100,7 @@ def main():
         fb, wb = 2.0 * f_avg * 1024.0, w_avg * 1024.0
         short = k.split("(")[0].replace("void ", "")[:80]
         plines.append(f"| `{short}` | {len(v)} | {f_avg:.1f} | {fb:.4e} | {w_avg:.1f} | {wb:.4e} |")
-        if DOMINANT in k and traffic is None:
+        if DOMINANT in k and DOMINANT_EXTRA in k and traffic is None:
             traffic = dict(hbm_bytes_per_launch=fb + wb, fetch_bytes=fb, write_bytes=wb, fetch_size_kib_raw=f_avg,
                            write_size_kib_raw=w_avg, launches=len(v), kernel=short,
                            correction="FETCH_SIZE x2 (gfx950, 16 B/lane coalesced stream), WRITE_SIZE exact; KiB -> bytes")
