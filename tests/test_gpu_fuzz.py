@@ -49,7 +49,14 @@ def test_random_fista_family(fos, seed):
         x_ref = orc.fista(A, b, "elasticnet", a1, a2, max_iter=iters, L=L)
         xh, h = fos.fista(prob, None, "elasticnet", a1, a2, max_iter=iters, L=L, return_history=True)
         _, h_ref = orc.fista(A, b, "elasticnet", a1, a2, max_iter=iters, L=L, return_history=True)
-        assert np.allclose(h["obj"], h_ref["obj"], rtol=TOL, atol=1e-9) and _data.rel(xh, x_ref) < TOL
+        # Objective resolution of a float32 pass over A: r = Ax - b is formed with an absolute error e, |e| ~ c*eps32*|b|
+        # (the products cancel against b), so 0.5|r|^2 carries |r||e| + 0.5|e|^2 = 2c*eps32*sqrt(obj*obj0) + c^2*eps32^2*
+        # obj0.  It only shows when the fit becomes near-exact (seed 613: m = 256 < n = 4100, no regularisation, the
+        # objective falls from 5e4 to 2e-6 in 26 iterations); the ITERATES keep the 1e-5 bound throughout.
+        ref = np.asarray(h_ref["obj"])
+        obj0 = 0.5 * float(b @ b)
+        bound = TOL * np.abs(ref) + 1e-6 * np.sqrt(np.abs(ref) * obj0) + 1e-12 * obj0
+        assert (np.abs(np.asarray(h["obj"]) - ref) <= bound).all() and _data.rel(xh, x_ref) < TOL
     elif kind == 1:     # adaptive restart with a random threshold, t_init_factor
         kw = dict(adaptive_restart=True, restart_threshold=float(rng.choice([0.5, 1.0, 2.0])),
                   t_init_factor=float(rng.choice([1.0, 0.5])))
