@@ -98,3 +98,95 @@ def test_random_lbfgs(fos, seed):
         A64 = A.astype(np.float64)
         x_star = np.linalg.solve(A64.T @ A64 + a2 * np.eye(n), A64.T @ b.astype(np.float64))
         assert _data.rel(s.x_, x_star) < 1e-4
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FOS_FUZZ_BT_SEEDS", "40"))))
+def test_random_backtracking(fos, seed):
+    """Armijo backtracking (matrix-core batch where the shape allows, one candidate per pass otherwise) against the
+    oracle: per-iteration shrink counts and iterates, judged up to the reference's first float64-noise event (a step
+    underflow: one search shrinking t by more than 1e-7, after which the reference is frozen at t ~ 1e-17 and its
+    own comparisons are rounding noise; or an iteration that changes the objective by < 1e-10 relative; see
+    tests/test_gpu_parity.py::_check_linesearch_counts).
+
+    Iterate errors are measured against the largest iterate norm the trajectory has reached: with t_init_factor > 1
+    the iterates can grow geometrically until the first rejection, and the accepted step then cancels y against
+    t*grad (seed 39: |y| = 2.1e3 -> |x| = 46), which amplifies the 2e-7 relative rounding of a float32 gradient by
+    the cancellation factor.  The error stays at 2e-7 of the trajectory's scale."""
+    from fastoptsolver_amd import iterative_solvers as its
+    rng = np.random.default_rng(3000 + seed)
+    A32, b32, A, b = _problem(rng)
+    n = A.shape[1]
+    lam = float(np.max(np.abs(A.T @ b))) or 1.0
+    a1 = float(rng.choice([0.0, 0.3, 0.05, 1e-3])) * lam
+    a2 = float(rng.choice([0.0, 0.5, 10.0]))
+    L = float(np.linalg.norm(A, 2) ** 2) or 1.0
+    iters = int(rng.integers(2, 25))
+    eta = float(rng.choice([0.5, 0.7, 0.9]))
+    tf = float(rng.choice([1.0, 2.0, 4.0]))
+    delta = float(rng.choice([0.0, 3.0]))               # 0 -> fista, else fista_delta
+    kw = dict(backtracking=True, eta=eta, t_init_factor=tf, max_iter=iters, return_history=True)
+    prob = fos.prepare(A32, b32)
+    if delta:
+        x, h = fos.fista_delta(prob, None, "elasticnet", a1, a2, delta, L=L, **kw)
+    else:
+        x, h = fos.fista(prob, None, "elasticnet", a1, a2, L=L, **kw)
+    ours = list(its.ls_call_iters)
+    ref = orc.FistaProblem(A, b, a1, a2)
+    st = ref.init_state(L, tf)
+    robust = []                                   # per iteration: were all of its Armijo comparisons decidable?
+    eps32 = float(np.finfo(np.float32).eps)
+    norm_b, norm_A = float(np.linalg.norm(b)), float(np.sqrt(L))
+
+    def backtrack(y, g, tau, eta_):
+        """FistaProblem.backtrack (iterative_solvers.py:183-197) that also records whether each comparison is decidable
+        from a float32 pass over A.  With d = x_tmp - y the test is  S = (1-C) g.d + 0.5|A d|^2 + 0.5 a2 |d|^2 <= 0.
+        A comparison counts as decidable when |S| exceeds
+          (a) 1e-5 of the size of its terms (resolution of the float32 sums themselves),
+          (b) 4*eps32*|A|(|A y| + |b|)*|d|: r = A y - b is formed in float32, so grad = A^T r carries an absolute error of
+              eps32*|A|(|Ay|+|b|) whatever the size of r, and g.d inherits it times |d| (seed 444: m = 2 rows, |r| =
+              3e-3|b|, grad good to 2e-5 only, g.d - a cancelling sum - off by 6 %),
+        and when d is not itself rounding noise (|d| > 1e-9|y|: seeds 611 / 657, a converged one-row problem where the
+        reference's own lhs - rhs has the opposite sign of S)."""
+        shrinks, ok = 0, True
+        grad_abs_err = eps32 * norm_A * (float(np.linalg.norm(A @ y)) + norm_b)
+        while True:
+            cand = ref.prox(y - tau * g, tau)
+            d = cand - y
+            Ad = A @ d
+            terms = [(1.0 - orc.ARMIJO_C) * float(g @ d), 0.5 * float(Ad @ Ad), 0.5 * a2 * float(d @ d)]
+            nd = float(np.linalg.norm(d))
+            ok = ok and abs(sum(terms)) > max(1e-5 * sum(abs(t) for t in terms), 4.0 * grad_abs_err * nd) \
+                and nd > 1e-9 * float(np.linalg.norm(y))
+            if orc.smooth_value(A, b, cand, a2) <= orc.smooth_value(A, b, y, a2) + orc.ARMIJO_C * float(g @ d):
+                break
+            tau *= eta_
+            shrinks += 1
+        ref.metrics.ls_iters.append(shrinks)
+        ref.metrics.ls_times.append(0.0)
+        robust.append(ok)
+        return tau
+
+    ref.backtrack = backtrack
+    xs, objs = [], []
+    for _ in range(iters):
+        (ref.step_delta(st, delta, backtracking=True, eta=eta) if delta else ref.step(st, backtracking=True, eta=eta))
+        xs.append(st.x.copy())
+        objs.append(ref.objective_inline(st.x))
+    counts = ref.metrics.ls_iters
+    assert len(ours) == len(counts) == iters
+    obj_prev, good = 0.5 * float(b @ b), iters
+    for k in range(iters):
+        progress = abs(objs[k] - obj_prev) / max(abs(objs[k]), 1e-300)
+        obj_prev = objs[k]
+        if eta ** counts[k] < 1e-7 or progress < 1e-10:
+            assert progress < 1e-10 or eta ** ours[k] < 1e-5, (seed, k, ours[k], counts[k])   # an underflow here too
+            good = k
+            break
+        if not robust[k]:          # a comparison below the resolution of a float32 pass over A: either outcome is
+            good = k               # legitimate, and the runs may part ways from here on
+            break
+        assert ours[k] == counts[k], (seed, k, ours[:k + 1], counts[:k + 1], A.shape, a1, a2, eta, tf, delta)
+    if good > 0:
+        xk = h["x"][good if not delta else good - 1]         # fista's history starts with x0, fista_delta's with x1
+        den = max(max(np.linalg.norm(v) for v in xs[:good]), 1e-12)
+        assert np.linalg.norm(np.asarray(xk) - xs[good - 1]) / den < TOL, (seed, good, A.shape, a1, a2, eta, tf, delta)
