@@ -148,7 +148,11 @@ class Problem:
         arr = (C.c_int32 * 8)()
         _lib.check(self.lib.fos_problem_plan(self.h, arr), "fos_problem_plan")
         keys = ("path", "threads", "chunks", "rows", "workgroups", "slabs", "nontemporal", "cus")
-        return dict(zip(keys, list(arr)))
+        plan = dict(zip(keys, list(arr)))
+        flags = plan["nontemporal"]
+        plan["nontemporal"] = flags & 1
+        plan["resident"] = (flags >> 1) & 1       # small problem: whole runs execute in one LDS-resident launch
+        return plan
 
     def tune(self, threads, chunks, rows, workgroups=0):
         _lib.check(self.lib.fos_problem_tune(self.h, threads, chunks, rows, workgroups), "fos_problem_tune")
@@ -275,6 +279,34 @@ class Fista:
         _lib.check(rc, "fos_fista_run_history")
         self._keep = work            # stays alive until the stream has consumed it (next sync)
         return self.prob.vec_out(xh), hist
+
+    def run_resident(self, iters, *, backtracking=False, eta=0.5, armijo_c=1e-2, grad_tol=0.0, record=False):
+        """Small problems: the whole run - backtracking, restart, stops, history included - in one launch of the
+        LDS-resident loop (fos_fista_run_resident).  Returns dict(done, tau, ls, taus[, x, hist]) with host lists for
+        the per-iteration integers / steps and device tensors for the history, or None when the problem does not fit.
+        Synchronises."""
+        if not self.prob.plan().get("resident"):
+            return None
+        dev = self.prob.device
+        iters = int(iters)
+        xh = torch.empty(max(iters, 1), self.prob.n_dev, dtype=torch.float64, device=dev) if record else None
+        hist = torch.empty(max(iters, 1), 4, dtype=torch.float64, device=dev) if record else None
+        ls = torch.zeros(max(iters, 1), dtype=torch.int32, device=dev)
+        taus = torch.zeros(max(iters, 1), dtype=torch.float64, device=dev)
+        done, tau = C.c_int32(0), C.c_double(0.0)
+        with torch.cuda.device(dev):
+            rc = self.lib.fos_fista_run_resident(self.h, iters, 1 if backtracking else 0, float(eta), float(armijo_c),
+                                                 float(grad_tol), ptr(xh), ptr(hist), ptr(ls), ptr(taus),
+                                                 C.byref(done), C.byref(tau))
+        if rc == -4:
+            return None
+        _lib.check(rc, "fos_fista_run_resident")
+        k = int(done.value)
+        out = dict(done=k, tau=float(tau.value), ls=ls[:k].cpu().tolist(), taus=taus[:k].cpu().tolist())
+        if record:
+            out["x"] = self.prob.vec_out(xh[:k])
+            out["hist"] = hist[:k]
+        return out
 
     def grad(self, dual=False):
         """Gradient pass at y_k; dual=True also leaves ||A x_k - b||^2 in status().rr_x (same pass over A)."""

@@ -55,6 +55,7 @@ SIGNATURES = {
     "fos_fista_run": (_i32, [_vp, _i32]),
     "fos_fista_history_workspace": (_i64, [_vp, _i32]),
     "fos_fista_run_history": (_i32, [_vp, _i32, _vp, _vp, _vp]),
+    "fos_fista_run_resident": (_i32, [_vp, _i32, _i32, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fos_fista_run_multi": (_i32, [C.POINTER(_vp), _i32, _i32]),
     "fos_fista_grad": (_i32, [_vp]),
     "fos_fista_grad_dual": (_i32, [_vp]),

@@ -15,6 +15,7 @@
 #include "gemv_pair.hpp"
 #include "lbfgs_kernels.hpp"
 #include "reduce_update.hpp"
+#include "resident.hpp"
 
 namespace {
 
@@ -106,6 +107,7 @@ struct fos_problem {
   int ncu = 256;
   // plan
   int path = 0;                      // 0 fused, 1 two-pass fallback
+  bool resident = false;             // small enough for the single-launch LDS-resident loop (resident.hpp)
   const MenuEntry* entry = nullptr;
   int nwg = 0;                       // workgroups of the fused kernel
   int nslabs = 0;
@@ -410,6 +412,7 @@ int fos_problem_create(fos_problem** out, const void* A, int64_t m, int64_t n, i
   }
   p->ncu = prop.multiProcessorCount;
   p->vec4 = (n % 4 == 0);
+  p->resident = fos::resident_fits(m, n) && getenv("FOS_NO_RESIDENT") == nullptr;
   const int epc = epc_of(a_dtype);
   const bool vec_ok = (n % epc == 0) && (lda % epc == 0) && ((reinterpret_cast<uintptr_t>(A) & 15u) == 0);
   const MenuEntry* e = vec_ok ? default_entry(a_dtype, n) : nullptr;
@@ -469,7 +472,7 @@ int fos_problem_plan(const fos_problem* p, int32_t plan[8]) {
   plan[3] = p->entry ? p->entry->r : 0;
   plan[4] = p->nwg;
   plan[5] = p->nslabs;
-  plan[6] = p->path == 0 ? 1 : 0;
+  plan[6] = (p->path == 0 ? 1 : 0) | (p->resident ? 2 : 0);
   plan[7] = p->ncu;
   return FOS_OK;
 }
@@ -551,6 +554,26 @@ int fos_power_iter(fos_problem* p, float* v_inout, int n_iter, double tol, doubl
   if (!p || !v_inout || !L_out || n_iter <= 0 || n_iter > 200)
     return fail(FOS_ERR_ARG, "fos_power_iter: bad argument (n_iter must be 1..200)");
   double* Lh = p->dscal + 32;   // n_iter + 1 slots
+  if (p->resident) {
+    // all iterations in one launch; the break rule (:57) is evaluated on the device
+    int* used_dev = reinterpret_cast<int*>(p->dscal + 240);
+    if (p->dtype == FOS_F32)
+      hipLaunchKernelGGL(fos::power_resident_kernel<float>, dim3(1), dim3(fos::RS_THREADS), 0, p->stream,
+                         (const float*)p->A, p->lda, (int)p->m, (int)p->n, v_inout, n_iter, tol, Lh, used_dev);
+    else
+      hipLaunchKernelGGL(fos::power_resident_kernel<fos::bf16_t>, dim3(1), dim3(fos::RS_THREADS), 0, p->stream,
+                         (const fos::bf16_t*)p->A, p->lda, (int)p->m, (int)p->n, v_inout, n_iter, tol, Lh, used_dev);
+    LAUNCH_CHECK();
+    std::vector<double> hL(n_iter);
+    int used = 0;
+    HIP_TRY(hipMemcpyAsync(&used, used_dev, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(hL.data(), Lh, (size_t)n_iter * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (used < 1 || used > n_iter) return fail(FOS_ERR_HIP, "fos_power_iter: resident kernel returned no result");
+    *L_out = hL[used - 1];
+    if (iters_out) *iters_out = used;
+    return FOS_OK;
+  }
   float* v = p->ybuf;
   // v = v0 / ||v0||   (iterative_solvers.py:51)
   hipLaunchKernelGGL(fos::power_normalize_kernel, dim3(1), dim3(1024), 0, p->stream, v_inout, (int)p->n, v, Lh + n_iter);
@@ -775,6 +798,52 @@ static int refresh_host_scalars(fos_fista* f, bool* stopped) {
   return FOS_OK;
 }
 
+// Whole run in ONE launch of ONE workgroup (resident.hpp): A, b and the iterate state stay in LDS.
+static int run_resident(fos_fista* f, int iters, double* x_hist, double* hist, fos::ResidentOpts opt = fos::ResidentOpts{}) {
+  fos_problem* p = f->p;
+  int rc = flush_pending(f);                   // device scalars must be current: the kernel continues from them
+  if (rc) return rc;
+  if (p->dtype == FOS_F32)
+    hipLaunchKernelGGL(fos::fista_resident_kernel<float>, dim3(1), dim3(fos::RS_THREADS), 0, p->stream,
+                       (const float*)p->A, p->lda, p->b, (int)p->m, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, iters,
+                       x_hist, hist, opt);
+  else
+    hipLaunchKernelGGL(fos::fista_resident_kernel<fos::bf16_t>, dim3(1), dim3(fos::RS_THREADS), 0, p->stream,
+                       (const fos::bf16_t*)p->A, p->lda, p->b, (int)p->m, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm,
+                       iters, x_hist, hist, opt);
+  LAUNCH_CHECK();
+  f->host_valid = false;                       // t, beta, k now live on the device only
+  f->y_valid = false;
+  f->plain_count = 0;
+  return FOS_OK;
+}
+
+int fos_fista_run_resident(fos_fista* f, int iters, int backtracking, double eta, double armijo_c, double grad_tol,
+                           double* x_hist, double* hist, int32_t* ls_iters, double* tau_hist, int32_t* iters_done,
+                           double* tau_out) {
+  if (!f || iters < 0 || !iters_done || !tau_out || (backtracking && !(eta > 0.0 && eta < 1.0)))
+    return fail(FOS_ERR_ARG, "fos_fista_run_resident: bad argument");
+  fos_problem* p = f->p;
+  if (!p->resident) return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_resident: problem does not fit the LDS-resident loop");
+  *iters_done = 0;
+  *tau_out = f->prm.tau;
+  if (iters == 0) return FOS_OK;
+  double* tau_dev = p->dscal + 241;
+  int* done_dev = reinterpret_cast<int*>(p->dscal + 242);
+  fos::ResidentOpts opt{backtracking ? 1 : 0, eta, armijo_c, grad_tol, ls_iters, tau_hist, tau_dev, done_dev};
+  int rc = run_resident(f, iters, x_hist, hist, opt);
+  if (rc) return rc;
+  int done = 0;
+  double tau = f->prm.tau;
+  HIP_TRY(hipMemcpyAsync(&done, done_dev, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipMemcpyAsync(&tau, tau_dev, sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  f->prm.tau = tau;                            // tau persists (iterative_solvers.py:197)
+  *iters_done = done;
+  *tau_out = tau;
+  return FOS_OK;
+}
+
 int64_t fos_fista_history_workspace(fos_fista* f, int iters) {
   if (!f || iters < 0) return -1;
   return ((int64_t)(iters + 1) * f->p->nwg + (int64_t)iters * f->nupd * 4) * (int64_t)sizeof(double);
@@ -784,6 +853,7 @@ int fos_fista_run_history(fos_fista* f, int iters, double* x_hist, double* hist,
   if (!f || iters < 0 || (iters > 0 && (!x_hist || !hist || !work)))
     return fail(FOS_ERR_ARG, "fos_fista_run_history: bad argument");
   fos_problem* p = f->p;
+  if (plain_run(f) && p->resident) return iters == 0 ? FOS_OK : run_resident(f, iters, x_hist, hist);
   if (!plain_run(f) || p->path != 0 || p->entry->dual == nullptr)
     return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_history: needs a plain run on the fused path with a DUAL kernel");
   if (iters == 0) return FOS_OK;
@@ -838,6 +908,7 @@ int fos_fista_run(fos_fista* f, int iters) {
   if (!f || iters < 0) return fail(FOS_ERR_ARG, "fos_fista_run: bad argument");
   fos_problem* p = f->p;
   if (iters == 0) return FOS_OK;
+  if (p->resident) return run_resident(f, iters, nullptr, nullptr);
   // Plain run: no data-dependent control (adaptive restart / stopping tolerances).  t_k and beta_k are then a fixed
   // sequence: the host passes beta_k to both kernels by value, and the scalar bookkeeping kernel runs once per call
   // instead of once per iteration (two launches per iteration instead of three).

@@ -150,6 +150,40 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
             del grad_call_times[k:]
         return st
 
+    # Small problems (A fits one CU's LDS): every host-driven feature - backtracking, gradient-norm stop, history, ISTA
+    # log - runs inside ONE launch of the LDS-resident loop; the host only unpacks what the device recorded.
+    if max_iter > 0:
+        ev = gtimer.start()
+        ls_t0 = time.perf_counter()
+        res = st.run_resident(max_iter, backtracking=backtracking, eta=eta, armijo_c=C,
+                              grad_tol=tol if (grad_tol_check and tol > 0.0) else 0.0,
+                              record=history is not None or log is not None)
+        if res is not None:
+            k = res["done"]
+            # one gradient per completed iteration, plus the one whose norm ended the run (ref:173-180)
+            ngrad = k + (1 if st.status().stopped == _lib.STOP_GRAD else 0)
+            gtimer.stop(ev, max(ngrad, 1))
+            gtimer.flush()
+            del grad_call_times[ngrad:]
+            if backtracking:                                     # ref:183-197: one search per completed iteration
+                share = (time.perf_counter() - ls_t0) / max(k, 1)
+                ls_call_iters.extend(int(v) for v in res["ls"])
+                ls_call_times.extend([share] * k)                # the device does not time its phases: equal shares
+            if history is not None or log is not None:
+                hs = res["hist"].cpu().numpy()
+                xs = res["x"]
+                as_tensor = like.tensor if hasattr(like, "tensor") else _core.is_tensor(like)    # ista passes x0 itself
+                rows = [_core.from_device_vec(xs[i], like) for i in range(k)] if as_tensor else list(xs.cpu().numpy())
+                if history is not None:
+                    history["x"].extend(rows)
+                    history["obj"].extend(history_obj(float(r[0]), float(r[2]), float(r[1])) for r in hs)
+                if log is not None:
+                    log["x"].extend(rows)
+                    log["t"].extend(res["taus"])
+                    log["delta"].extend(float(math.sqrt(r[3])) for r in hs)
+            return st
+        gtimer.pending.clear()
+
     # History without any per-iteration host round trip: x and the objective ingredients are recorded on the device
     # by the same two kernels of the plain run and read back once (ref:224-232, :319-322).
     plain = not (mode == _lib.MODE_FISTA and adaptive_restart) and tol == 0.0 and tol_ratio == 0.0

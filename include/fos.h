@@ -73,7 +73,8 @@ int fos_problem_create(fos_problem** out, const void* A, int64_t m, int64_t n, i
                        const float* b, void* stream);
 int fos_problem_destroy(fos_problem* p);
 /* plan[0..7] = {path (0 fused single pass, 1 two-pass fallback), threads, chunks/thread, rows/step,
- *               workgroups, slabs, nontemporal, CUs} */
+ *               workgroups, slabs, flags (bit 0: non-temporal loads; bit 1: small enough for the single-launch
+ *               LDS-resident loop that fos_fista_run / _run_history / fos_power_iter then use), CUs} */
 int fos_problem_plan(const fos_problem* p, int32_t plan[8]);
 /* Benchmark/tuning override of the fused-kernel geometry; returns FOS_ERR_UNSUPPORTED if not instantiated. */
 int fos_problem_tune(fos_problem* p, int threads, int chunks, int rows, int workgroups);
@@ -135,6 +136,17 @@ int fos_fista_run(fos_fista* f, int iters);
  * Only for runs without data-dependent control (no adaptive restart, no stopping tolerance) on the fused path with a
  * DUAL kernel; otherwise FOS_ERR_UNSUPPORTED and the caller drives the split form below.  Enqueues only. */
 int64_t fos_fista_history_workspace(fos_fista* f, int iters);
+/* Small problems (fos_problem_plan flags bit 1: A fits one CU's LDS, n <= 64): up to `iters` iterations with EVERY
+ * option of the reference's loops inside ONE launch of ONE workgroup - backtracking (:183-197, the reference's own
+ * comparison g(x_tmp) <= g(y) + C*grad.(x_tmp - y) in fp64; `armijo_c` = its module global C), adaptive restart and
+ * the step / ratio stops of fos_fista_params, the gradient-norm stop (grad_tol > 0, :179), history.  A, b and the
+ * iterate state stay in LDS for the whole run.  Optional device outputs (NULL to skip): x_hist iters x n doubles,
+ * hist iters x 4 doubles (layout of fos_fista_run_history), ls_iters iters int32 (shrinks per search), tau_hist iters
+ * doubles (step used).  Synchronises; *iters_done = iterations completed (a stop ends the run early), *tau_out = the
+ * step after the last search, which the handle keeps.  FOS_ERR_UNSUPPORTED when the problem does not fit. */
+int fos_fista_run_resident(fos_fista* f, int iters, int backtracking, double eta, double armijo_c, double grad_tol,
+                           double* x_hist, double* hist, int32_t* ls_iters, double* tau_hist, int32_t* iters_done,
+                           double* tau_out);
 int fos_fista_run_history(fos_fista* f, int iters, double* x_hist, double* hist, void* work);
 /* Regularisation path: nv <= 4 state machines bound to the SAME fos_problem (different alpha1 / alpha2 / tau) advance
  * `iters` plain iterations in lockstep; every iteration reads A from HBM once for all of them (multi-vector form of
