@@ -689,3 +689,74 @@ def test_ista_with_the_reference_users_numpy_closures(fos):
         assert isinstance(x, np.ndarray) and x.dtype == np.float64
         assert _data.rel(x, fx[key + "/x"]) < TOL, key
         assert len(log["x"]) == 41 and len(log["delta"]) == 40
+
+
+# --------------------------------------------------------------------------------------------------
+# LDS-resident loop (small problems): continuity with the multi-launch state machine, API semantics
+# --------------------------------------------------------------------------------------------------
+def test_resident_loop_and_split_entry_points_share_one_state(fos):
+    """10 iterations inside the resident launch, 10 through grad()/update(), 10 resident again == 30 oracle
+    iterations: the kernel continues from and leaves behind the same device state as the multi-launch path."""
+    from fastoptsolver_amd import _core, _lib
+    A, b, fx = _data.problem("tiny")
+    lam = float(np.max(np.abs(A.T @ b)))
+    L = float(fx["tiny/L"])
+    a1, a2 = 0.05 * lam, 0.5
+    prob = fos.prepare(A, b)
+    assert prob.plan()["resident"] == 1
+    for mode, delta in ((_lib.MODE_FISTA, 0.0), (_lib.MODE_DELTA, 3.0)):
+        st = _core.Fista(prob)
+        st.reset(1.0 / (L + a2), a1, a2, mode=mode, prox_kind=_lib.PROX_L1, delta=delta)
+        st.run(10)                                   # resident
+        for _ in range(10):                          # split entry points (two launches + bookkeeping per iteration)
+            st.grad()
+            st.update()
+        st.run(10)                                   # resident again
+        assert int(st.status().k) == 30
+        if mode == _lib.MODE_FISTA:
+            x_ref = orc.fista(A, b, "elasticnet", a1, a2, max_iter=30, L=L)
+        else:
+            x_ref = orc.fista_delta(A, b, "elasticnet", a1, a2, delta, max_iter=30, L=L)
+        assert _data.rel(st.x_tensor().cpu().numpy(), x_ref) < TOL, mode
+
+
+def test_resident_run_reports_stops_steps_and_counts(fos):
+    from fastoptsolver_amd import _core, _lib
+    A, b, fx = _data.problem("tiny")
+    lam = float(np.max(np.abs(A.T @ b)))
+    L = float(fx["tiny/L"])
+    prob = fos.prepare(A, b)
+    st = _core.Fista(prob)
+    # ISTA with a generous first step: 2 genuine shrinks, then the step-size stop after 11 iterations (no momentum, so
+    # none of the reference's step-underflow events, DESIGN §5)
+    a1, a2, tol = 0.05 * lam, 0.5, 1e-5
+    st.reset(8.0 / (L + a2), a1, a2, mode=_lib.MODE_ISTA, prox_kind=_lib.PROX_L1, tol_step=tol)
+    res = st.run_resident(400, backtracking=True, eta=0.5, armijo_c=1e-2, record=True)
+    (x_ref, log), met = orc.ista(np.zeros(A.shape[1]), lambda z: orc.smooth_value(A, b, z, a2),
+                                 lambda z: orc.gram_gradient(A, z, b, a2)[0], lambda v, t: orc.prox_l1(v, t * a1),
+                                 L + a2, backtracking=True, eta=0.5, t_init_factor=8.0, max_iter=400, tol=tol,
+                                 return_history=True, return_metrics=True)
+    k = len(log["delta"])
+    assert res["done"] == k < 400 and st.status().stopped == _lib.STOP_STEP                 # delta < tol (:122)
+    assert sum(res["ls"]) == met["ls_iters_total"] > 0
+    assert np.allclose(res["taus"], log["t"][1:], rtol=1e-12) and res["tau"] == res["taus"][-1]
+    assert res["x"].shape == (k, A.shape[1]) and _data.rel(res["x"][-1].cpu().numpy(), x_ref) < TOL
+    assert np.allclose(np.sqrt(res["hist"][:, 3].cpu().numpy()), log["delta"], rtol=1e-4, atol=1e-12)
+    assert st.run_resident(5)["done"] == 0               # a stopped solver stays stopped
+    # a problem beyond the LDS budget reports "not resident" and the caller falls back to the multi-launch loop
+    big = fos.prepare(np.zeros((4097, 8), dtype=np.float32), np.zeros(4097, dtype=np.float32))
+    assert big.plan()["resident"] == 0 and _core.Fista(big).run_resident(1) is None
+
+
+def test_resident_and_multi_launch_paths_agree(fos, monkeypatch):
+    """FOS_NO_RESIDENT=1 keeps small problems on the streaming kernels: same iterates either way."""
+    A, b, fx = _data.problem("tiny")
+    lam = float(np.max(np.abs(A.T @ b)))
+    L = float(fx["tiny/L"])
+    kw = dict(max_iter=60, L=L, backtracking=True, t_init_factor=2.0, return_history=True)
+    x1, h1 = fos.fista(A, b, "lasso", 0.05 * lam, 0.0, **kw)
+    monkeypatch.setenv("FOS_NO_RESIDENT", "1")
+    prob = fos.prepare(A, b)
+    assert prob.plan()["resident"] == 0
+    x2, h2 = fos.fista(prob, None, "lasso", 0.05 * lam, 0.0, **kw)
+    assert _data.rel(x1, x2) < 1e-6 and np.allclose(h1["obj"], h2["obj"], rtol=1e-6)
