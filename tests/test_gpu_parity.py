@@ -760,3 +760,22 @@ def test_resident_and_multi_launch_paths_agree(fos, monkeypatch):
     assert prob.plan()["resident"] == 0
     x2, h2 = fos.fista(prob, None, "lasso", 0.05 * lam, 0.0, **kw)
     assert _data.rel(x1, x2) < 1e-6 and np.allclose(h1["obj"], h2["obj"], rtol=1e-6)
+
+
+def test_resident_loop_with_bf16_storage(fos):
+    """A stored in bf16 also runs in the LDS-resident loop (converted to fp32 once, when it is copied into LDS)."""
+    A, b, fx = _data.problem("tiny")
+    A16 = torch.as_tensor(A.astype(np.float32)).to(torch.bfloat16)
+    Aq = A16.to(torch.float64).numpy()
+    lam = float(np.max(np.abs(Aq.T @ b)))
+    L = float(np.linalg.norm(Aq, 2) ** 2)
+    prob = fos.prepare(A16.cuda(), b)
+    assert prob.dtype == "bf16" and prob.plan()["resident"] == 1
+    np.random.seed(3)
+    assert fos.estimate_lipschitz(prob) == pytest.approx(orc.estimate_lipschitz(Aq, v0=np.random.RandomState(3).randn(16)),
+                                                         rel=1e-6)
+    for kw in (dict(), dict(backtracking=True, t_init_factor=2.0, eta=0.7)):
+        x, h = fos.fista(prob, None, "elasticnet", 0.05 * lam, 0.5, max_iter=40, L=L, return_history=True, **kw)
+        x_ref, h_ref = orc.fista(Aq, b, "elasticnet", 0.05 * lam, 0.5, max_iter=40, L=L, return_history=True, **kw)
+        assert _data.rel(x.cpu().numpy() if torch.is_tensor(x) else x, x_ref) < TOL, kw
+        assert np.allclose(h["obj"], h_ref["obj"], rtol=TOL), kw
