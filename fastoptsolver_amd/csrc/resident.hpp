@@ -56,7 +56,7 @@ __global__ __launch_bounds__(RS_THREADS) void fista_resident_kernel(const T* __r
   __shared__ float a_s[RS_MAX_A];
   __shared__ float b_s[RS_MAX_M];
   __shared__ double y_s[RS_MAX_N], xc_s[RS_MAX_N], xp_s[RS_MAX_N], g_s[RS_MAX_N], tmp_s[RS_MAX_N];
-  __shared__ double sc_s[4];
+  __shared__ double sc_s[5];       // ||Ay-b||^2, ||grad||^2, ||y||^2, grad.dlt, ||x_tmp||^2
   __shared__ double red[RS_WAVES][RS_CHUNK + 1];
   __shared__ int stop_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -123,8 +123,8 @@ __global__ __launch_bounds__(RS_THREADS) void fista_resident_kernel(const T* __r
   };
 
   for (int it = 0; it < iters; ++it) {
-    // ---- phase A: r = A y - b -----------------------------------------------------------------------------------
-    const double rr = block_total(residual(y_s));
+    // ---- phase A: r = A y - b (per-thread rows; ||r||^2 rides along with the first column chunk's reduction) --------
+    double rr_part = residual(y_s);
     // ---- phase B: g = A^T r, RS_CHUNK columns per block reduction ---------------------------------------------------
     for (int c0 = 0; c0 < n; c0 += RS_CHUNK) {
       double p[RS_CHUNK];
@@ -145,6 +145,10 @@ __global__ __launch_bounds__(RS_THREADS) void fista_resident_kernel(const T* __r
         p[c] = wave_sum(p[c]);
         if (lane == 0) red[wave][c] = p[c];
       }
+      if (c0 == 0) {
+        rr_part = wave_sum(rr_part);
+        if (lane == 0) red[wave][RS_CHUNK] = rr_part;
+      }
       __syncthreads();
       if (tid < RS_CHUNK && c0 + tid < n) {
         double tot = 0.0;
@@ -152,25 +156,32 @@ __global__ __launch_bounds__(RS_THREADS) void fista_resident_kernel(const T* __r
         for (int w = 0; w < RS_WAVES; ++w) tot += red[w][tid];
         g_s[c0 + tid] = tot;
       }
+      if (c0 == 0 && tid == RS_CHUNK) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) tot += red[w][RS_CHUNK];
+        sc_s[0] = tot;                                   // ||A y - b||^2
+      }
       __syncthreads();
     }
+    const double rr = sc_s[0];
     // ---- gradient-norm stop (:179, before the update) and Armijo search (:183-197) -------------------------------
     if (opt.grad_tol > 0.0 || opt.backtracking) {
       if (wave == 0) {
         const double y = lane < n ? y_s[lane] : 0.0;
         const double gfl = lane < n ? g_s[lane] + sa2 * y : 0.0;
         const double gn2 = wave_sum(gfl * gfl), y2 = wave_sum(y * y);
-        if (lane == 0) { sc_s[0] = gn2; sc_s[1] = y2; }
+        if (lane == 0) { sc_s[1] = gn2; sc_s[2] = y2; }
       }
       __syncthreads();
-      if (opt.grad_tol > 0.0 && sqrt(sc_s[0]) < opt.grad_tol) {      // uniform: every thread reads the same LDS value
+      if (opt.grad_tol > 0.0 && sqrt(sc_s[1]) < opt.grad_tol) {      // uniform: every thread reads the same LDS value
         stop = STOP_GRAD;
         break;
       }
       if (opt.backtracking) {
         // the reference's comparison itself, g(x_tmp) <= g(y) + C*grad.(x_tmp - y) with g evaluated twice (:187-191),
         // in fp64 on the LDS copy of A; tau persists across iterations (:197)
-        const double g_y = 0.5 * rr + 0.5 * sa2 * sc_s[1];
+        const double g_y = 0.5 * rr + 0.5 * sa2 * sc_s[2];
         int shrinks = 0;
         while (true) {
           if (wave == 0) {
@@ -185,10 +196,10 @@ __global__ __launch_bounds__(RS_THREADS) void fista_resident_kernel(const T* __r
               dl = xt - y;
             }
             const double gd = wave_sum(gfl * dl), x2t = wave_sum(xt * xt);
-            if (lane == 0) { sc_s[2] = gd; sc_s[3] = x2t; }
+            if (lane == 0) { sc_s[3] = gd; sc_s[4] = x2t; }
           }
           __syncthreads();
-          const double gd = sc_s[2], x2t = sc_s[3];                  // into registers before the barriers below
+          const double gd = sc_s[3], x2t = sc_s[4];                  // into registers before the barriers below
           const double rr_t = block_total(residual(tmp_s));
           const double lhs = 0.5 * rr_t + 0.5 * sa2 * x2t;
           if (lhs <= g_y + opt.armijo_c * gd || shrinks >= RS_MAX_SHRINKS) break;
