@@ -19,7 +19,7 @@ def run(name, A, b, iters=2000):
           f"{(t1 - t0) / iters * 1e6:6.2f} us/iteration)  plan {prob.plan()}", flush=True)
 
 A, b, _ = generate_correlated_boston_like_data()
-run("boston 1000x5 (fallback)", A, b)
+run("boston 1000x5 (resident)", A, b)
 rng = np.random.default_rng(0)
 for m, n in ((1024, 256), (4096, 1024), (16384, 2048)):
     A = rng.standard_normal((m, n)).astype(np.float32); b = rng.standard_normal(m).astype(np.float32)
