@@ -9,7 +9,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "fos_api.hip")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("fos_api.hip", "gemv_pair.hpp", "reduce_update.hpp", "lbfgs_kernels.hpp")]
+# every source the one translation unit includes: any newer file triggers a rebuild
+DEPS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith((".hip", ".hpp")))
 DEPS.append(os.path.join(os.path.dirname(HERE), "include", "fos.h"))
 OUT = os.path.join(HERE, "libfos_hip.so")
 

@@ -803,14 +803,14 @@ static int run_resident(fos_fista* f, int iters, double* x_hist, double* hist, f
   fos_problem* p = f->p;
   int rc = flush_pending(f);                   // device scalars must be current: the kernel continues from them
   if (rc) return rc;
-  if (p->dtype == FOS_F32)
-    hipLaunchKernelGGL(fos::fista_resident_kernel<float>, dim3(1), dim3(fos::RS_THREADS), 0, p->stream,
-                       (const float*)p->A, p->lda, p->b, (int)p->m, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, iters,
-                       x_hist, hist, opt);
-  else
-    hipLaunchKernelGGL(fos::fista_resident_kernel<fos::bf16_t>, dim3(1), dim3(fos::RS_THREADS), 0, p->stream,
-                       (const fos::bf16_t*)p->A, p->lda, p->b, (int)p->m, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm,
-                       iters, x_hist, hist, opt);
+  const bool small = p->n <= fos::RS_CHUNK && p->m <= fos::RS_SMALL_M;    // rows of A in registers (resident.hpp)
+#define FOS_RS_LAUNCH(T, SMALL)                                                                                          \
+  hipLaunchKernelGGL((fos::fista_resident_kernel<T, SMALL>), dim3(1), dim3(fos::RS_THREADS), 0, p->stream,               \
+                     (const T*)p->A, p->lda, p->b, (int)p->m, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, iters,    \
+                     x_hist, hist, opt)
+  if (p->dtype == FOS_F32) { if (small) FOS_RS_LAUNCH(float, true); else FOS_RS_LAUNCH(float, false); }
+  else { if (small) FOS_RS_LAUNCH(fos::bf16_t, true); else FOS_RS_LAUNCH(fos::bf16_t, false); }
+#undef FOS_RS_LAUNCH
   LAUNCH_CHECK();
   f->host_valid = false;                       // t, beta, k now live on the device only
   f->y_valid = false;

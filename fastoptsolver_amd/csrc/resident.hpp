@@ -25,6 +25,7 @@ constexpr int RS_MAX_N = 64;          // one wave owns all coordinates in phase 
 constexpr int RS_MAX_M = 4096;        // b in LDS: 16 KiB
 constexpr int RS_MAX_A = 10240;       // floats of A in LDS (40 KiB) incl. the odd row stride
 constexpr int RS_CHUNK = 8;           // columns reduced per block reduction
+constexpr int RS_SMALL_M = 2048;      // n <= RS_CHUNK and m <= this: rows of A live in registers (4 rows per thread)
 constexpr int RS_MAX_SHRINKS = 4096;  // exit condition of the Armijo loop every wave reaches (NaN inputs would spin)
 
 // Per-launch options of the resident loop beyond FistaParams (all host-driven features of the multi-launch path).
@@ -39,6 +40,45 @@ struct ResidentOpts {
   int* iters_done;         // nullable, 1 int: iterations completed by this launch
 };
 
+// Wave-wide sums on the DPP path (no LDS crossbar): a __shfl_xor of a double is two ds_bpermute round trips of ~150
+// cycles, and the loop's reductions were 12 such dependent round trips per iteration - most of its 4-5 us.  Here each
+// step is two v_mov_b32_dpp and one v_add_f64: row_shr 1/2/4/8 leave every 16-lane row's total in its lane 15,
+// row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3) carry the totals up to lane 63, v_readlane broadcasts it.
+// Lanes without a DPP source receive 0.  Fixed order -> deterministic.
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_fetch(double v) {
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, ROW_MASK, 0xF, false);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+template <int N>
+__device__ inline void wave_sum_n(double (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_fetch<0x111, 0xF>(v[i]);     // row_shr:1
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_fetch<0x112, 0xF>(v[i]);     // row_shr:2
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_fetch<0x114, 0xF>(v[i]);     // row_shr:4
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_fetch<0x118, 0xF>(v[i]);     // row_shr:8
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_fetch<0x142, 0xA>(v[i]);     // row_bcast:15 into rows 1 and 3
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_fetch<0x143, 0xC>(v[i]);     // row_bcast:31 into rows 2 and 3
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const long long bits = __double_as_longlong(v[i]);
+    const int lo = __builtin_amdgcn_readlane((int)bits, 63), hi = __builtin_amdgcn_readlane((int)(bits >> 32), 63);
+    v[i] = __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+  }
+}
+__device__ inline double wave_sum_dpp(double x) {
+  double v[1] = {x};
+  wave_sum_n(v);
+  return v[0];
+}
+
 __host__ __device__ inline int rs_stride(int n) { return n | 1; }   // odd row stride: conflict-free column walks
 inline bool resident_fits(int64_t m, int64_t n) {
   return n >= 1 && n <= RS_MAX_N && m >= 1 && m <= RS_MAX_M && m * rs_stride((int)n) <= RS_MAX_A;
@@ -46,7 +86,9 @@ inline bool resident_fits(int64_t m, int64_t n) {
 
 // hist (nullable): iters x 4 doubles { ||A x - b||^2, ||x||_1, ||x||_2^2, ||x - x_before||^2 } per iterate;
 // x_hist (nullable): iters x n doubles.  Iterations after a stop are not executed (state untouched, rows not written).
-template <typename T>
+// SMALL (n <= RS_CHUNK): every thread keeps its rows of A and b in registers and the loop reads LDS only for the
+// n-vectors - the shape of the reference's own problems (n = 5).
+template <typename T, bool SMALL>
 __global__ __launch_bounds__(RS_THREADS) void fista_resident_kernel(const T* __restrict__ A, int64_t lda,
                                                                    const float* __restrict__ b, int m, int n,
                                                                    double* __restrict__ x_cur, double* __restrict__ x_prev,
@@ -92,10 +134,34 @@ __global__ __launch_bounds__(RS_THREADS) void fista_resident_kernel(const T* __r
   __syncthreads();
 
   // residual of the vector v_s over this thread's rows; r_loc keeps them for phase B
-  constexpr int RPT = (RS_MAX_M + RS_THREADS - 1) / RS_THREADS;      // rows per thread (8)
+  constexpr int RPT = SMALL ? RS_SMALL_M / RS_THREADS : (RS_MAX_M + RS_THREADS - 1) / RS_THREADS;   // rows per thread: 4 / 8
   double r_loc[RPT];
+  float a_reg[SMALL ? RPT : 1][RS_CHUNK], b_reg[SMALL ? RPT : 1];
+  if constexpr (SMALL) {
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int row = tid + q * RS_THREADS;
+#pragma unroll
+      for (int c = 0; c < RS_CHUNK; ++c) a_reg[q][c] = (row < m && c < n) ? a_s[row * ns + c] : 0.f;   // zero rows / columns
+      b_reg[q] = row < m ? b_s[row] : 0.f;
+    }
+  }
   auto residual = [&](const double* v_s) {
     double rr = 0.0;
+    if constexpr (SMALL) {
+      double v[RS_CHUNK];
+#pragma unroll
+      for (int c = 0; c < RS_CHUNK; ++c) v[c] = c < n ? v_s[c] : 0.0;
+#pragma unroll
+      for (int q = 0; q < RPT; ++q) {
+        double acc = -(double)b_reg[q];
+#pragma unroll
+        for (int c = 0; c < RS_CHUNK; ++c) acc += (double)a_reg[q][c] * v[c];
+        r_loc[q] = acc;                          // rows beyond m: a = 0, b = 0 -> r = 0
+        rr += acc * acc;
+      }
+      return rr;
+    }
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
       const int row = tid + q * RS_THREADS;
@@ -112,7 +178,7 @@ __global__ __launch_bounds__(RS_THREADS) void fista_resident_kernel(const T* __r
   };
   // block sum of one double per thread -> every thread gets the total (uses red[][RS_CHUNK], two barriers)
   auto block_total = [&](double v) {
-    v = wave_sum(v);
+    v = wave_sum_dpp(v);
     if (lane == 0) red[wave][RS_CHUNK] = v;
     __syncthreads();
     double tot = 0.0;
@@ -130,24 +196,34 @@ __global__ __launch_bounds__(RS_THREADS) void fista_resident_kernel(const T* __r
       double p[RS_CHUNK];
 #pragma unroll
       for (int c = 0; c < RS_CHUNK; ++c) p[c] = 0.0;
+      if constexpr (SMALL) {
 #pragma unroll
-      for (int q = 0; q < RPT; ++q) {
-        const int row = tid + q * RS_THREADS;
-        if (row < m) {
-          const float* ar = a_s + row * ns + c0;
+        for (int q = 0; q < RPT; ++q)
 #pragma unroll
-          for (int c = 0; c < RS_CHUNK; ++c)
-            if (c0 + c < n) p[c] += (double)ar[c] * r_loc[q];
+          for (int c = 0; c < RS_CHUNK; ++c) p[c] += (double)a_reg[q][c] * r_loc[q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+          const int row = tid + q * RS_THREADS;
+          if (row < m) {
+            const float* ar = a_s + row * ns + c0;
+#pragma unroll
+            for (int c = 0; c < RS_CHUNK; ++c)
+              if (c0 + c < n) p[c] += (double)ar[c] * r_loc[q];
+          }
         }
       }
+      {
+        double v[RS_CHUNK + 1];
 #pragma unroll
-      for (int c = 0; c < RS_CHUNK; ++c) {
-        p[c] = wave_sum(p[c]);
-        if (lane == 0) red[wave][c] = p[c];
-      }
-      if (c0 == 0) {
-        rr_part = wave_sum(rr_part);
-        if (lane == 0) red[wave][RS_CHUNK] = rr_part;
+        for (int c = 0; c < RS_CHUNK; ++c) v[c] = p[c];
+        v[RS_CHUNK] = rr_part;                           // only chunk 0's value is used
+        wave_sum_n(v);
+        if (lane == 0) {
+#pragma unroll
+          for (int c = 0; c <= RS_CHUNK; ++c)
+            if (c < RS_CHUNK || c0 == 0) red[wave][c] = v[c];
+        }
       }
       __syncthreads();
       if (tid < RS_CHUNK && c0 + tid < n) {
@@ -170,8 +246,9 @@ __global__ __launch_bounds__(RS_THREADS) void fista_resident_kernel(const T* __r
       if (wave == 0) {
         const double y = lane < n ? y_s[lane] : 0.0;
         const double gfl = lane < n ? g_s[lane] + sa2 * y : 0.0;
-        const double gn2 = wave_sum(gfl * gfl), y2 = wave_sum(y * y);
-        if (lane == 0) { sc_s[1] = gn2; sc_s[2] = y2; }
+        double gy[2] = {gfl * gfl, y * y};
+        wave_sum_n(gy);
+        if (lane == 0) { sc_s[1] = gy[0]; sc_s[2] = gy[1]; }
       }
       __syncthreads();
       if (opt.grad_tol > 0.0 && sqrt(sc_s[1]) < opt.grad_tol) {      // uniform: every thread reads the same LDS value
@@ -195,8 +272,9 @@ __global__ __launch_bounds__(RS_THREADS) void fista_resident_kernel(const T* __r
               tmp_s[lane] = xt;
               dl = xt - y;
             }
-            const double gd = wave_sum(gfl * dl), x2t = wave_sum(xt * xt);
-            if (lane == 0) { sc_s[3] = gd; sc_s[4] = x2t; }
+            double gx[2] = {gfl * dl, xt * xt};
+            wave_sum_n(gx);
+            if (lane == 0) { sc_s[3] = gx[0]; sc_s[4] = gx[1]; }
           }
           __syncthreads();
           const double gd = sc_s[3], x2t = sc_s[4];                  // into registers before the barriers below
@@ -222,7 +300,9 @@ __global__ __launch_bounds__(RS_THREADS) void fista_resident_kernel(const T* __r
         if (prm.prox_kind == PROX_ENET) xn *= 1.0 / (1.0 + tau * prm.alpha2);
         d = xn - xc;
       }
-      const double s0 = wave_sum(d * d), s1 = wave_sum(gf * gf), s2 = wave_sum(fabs(xn)), s3 = wave_sum(xn * xn);
+      double sums[4] = {d * d, gf * gf, fabs(xn), xn * xn};
+      wave_sum_n(sums);
+      const double s0 = sums[0], s1 = sums[1], s2 = sums[2], s3 = sums[3];
       // every lane computes the same scalars (wave_sum broadcasts), so no further exchange is needed
       const double step = sqrt(s0);
       const double prev = this_step;
@@ -347,10 +427,10 @@ __global__ __launch_bounds__(RS_THREADS) void power_resident_kernel(const T* __r
             if (c0 + c < n) p[c] += (double)ar[c] * r_loc[q];
         }
       }
+      wave_sum_n(p);
+      if (lane == 0) {
 #pragma unroll
-      for (int c = 0; c < RS_CHUNK; ++c) {
-        p[c] = wave_sum(p[c]);
-        if (lane == 0) red[wave][c] = p[c];
+        for (int c = 0; c < RS_CHUNK; ++c) red[wave][c] = p[c];
       }
       __syncthreads();
       if (tid < RS_CHUNK && c0 + tid < n) {
