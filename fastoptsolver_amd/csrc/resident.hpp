@@ -40,45 +40,6 @@ struct ResidentOpts {
   int* iters_done;         // nullable, 1 int: iterations completed by this launch
 };
 
-// Wave-wide sums on the DPP path (no LDS crossbar): a __shfl_xor of a double is two ds_bpermute round trips of ~150
-// cycles, and the loop's reductions were 12 such dependent round trips per iteration - most of its 4-5 us.  Here each
-// step is two v_mov_b32_dpp and one v_add_f64: row_shr 1/2/4/8 leave every 16-lane row's total in its lane 15,
-// row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3) carry the totals up to lane 63, v_readlane broadcasts it.
-// Lanes without a DPP source receive 0.  Fixed order -> deterministic.
-template <int CTRL, int ROW_MASK>
-__device__ inline double dpp_fetch(double v) {
-  const long long bits = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, CTRL, ROW_MASK, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, ROW_MASK, 0xF, false);
-  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
-}
-template <int N>
-__device__ inline void wave_sum_n(double (&v)[N]) {
-#pragma unroll
-  for (int i = 0; i < N; ++i) v[i] += dpp_fetch<0x111, 0xF>(v[i]);     // row_shr:1
-#pragma unroll
-  for (int i = 0; i < N; ++i) v[i] += dpp_fetch<0x112, 0xF>(v[i]);     // row_shr:2
-#pragma unroll
-  for (int i = 0; i < N; ++i) v[i] += dpp_fetch<0x114, 0xF>(v[i]);     // row_shr:4
-#pragma unroll
-  for (int i = 0; i < N; ++i) v[i] += dpp_fetch<0x118, 0xF>(v[i]);     // row_shr:8
-#pragma unroll
-  for (int i = 0; i < N; ++i) v[i] += dpp_fetch<0x142, 0xA>(v[i]);     // row_bcast:15 into rows 1 and 3
-#pragma unroll
-  for (int i = 0; i < N; ++i) v[i] += dpp_fetch<0x143, 0xC>(v[i]);     // row_bcast:31 into rows 2 and 3
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const long long bits = __double_as_longlong(v[i]);
-    const int lo = __builtin_amdgcn_readlane((int)bits, 63), hi = __builtin_amdgcn_readlane((int)(bits >> 32), 63);
-    v[i] = __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
-  }
-}
-__device__ inline double wave_sum_dpp(double x) {
-  double v[1] = {x};
-  wave_sum_n(v);
-  return v[0];
-}
-
 __host__ __device__ inline int rs_stride(int n) { return n | 1; }   // odd row stride: conflict-free column walks
 inline bool resident_fits(int64_t m, int64_t n) {
   return n >= 1 && n <= RS_MAX_N && m >= 1 && m <= RS_MAX_M && m * rs_stride((int)n) <= RS_MAX_A;
