@@ -79,18 +79,6 @@ __device__ inline u32x4 load16(const void* p) {
   else return *reinterpret_cast<const u32x4*>(p);
 }
 
-// Sum over the 64 lanes of a wave; every lane gets the total (butterfly, fixed order -> deterministic).
-__device__ inline float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-__device__ inline double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
 // Wave-wide fp64 sums on the DPP path (no LDS crossbar), for the latency-bound kernels (resident loop, L-BFGS two-loop):
 // a __shfl_xor of a double is two ds_bpermute round trips of ~150 cycles, and the resident loop's reductions were 12
 // such dependent round trips per iteration - most of its 4-5 us.  Here each step is two v_mov_b32_dpp and one
@@ -130,6 +118,14 @@ __device__ inline double wave_sum_dpp(double x) {
   wave_sum_n(v);
   return v[0];
 }
+
+// Sum over the 64 lanes of a wave; every lane gets the total (fp32: butterfly; fixed order -> deterministic).
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ inline double wave_sum(double v) { return wave_sum_dpp(v); }   // fp64: DPP path (see above)
 
 // T: element type of A.  THREADS: workgroup size.  K: 16-byte chunks per thread per row.  R: rows per step.
 // Requirements (checked on the host): n % EPC == 0, lda % EPC == 0, A 16-byte aligned, n <= K*THREADS*EPC.
