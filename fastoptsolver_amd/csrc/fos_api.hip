@@ -511,6 +511,16 @@ int fos_gemv_pair(fos_problem* p, const float* y, float alpha2, float* grad, dou
 
 int fos_gemv_pair_f64(fos_problem* p, const double* y, double alpha2, float* grad, double* rr_out) {
   if (!p || !y || !grad) return fail(FOS_ERR_ARG, "fos_gemv_pair_f64: null");
+  if (p->resident) {                           // small problem: one launch, fp64 throughout (resident.hpp)
+    if (p->dtype == FOS_F32)
+      hipLaunchKernelGGL(fos::gemv_pair_resident_kernel<float>, dim3(1), dim3(fos::RS_THREADS), 0, p->stream,
+                         (const float*)p->A, p->lda, p->b, (int)p->m, (int)p->n, y, alpha2, grad, rr_out);
+    else
+      hipLaunchKernelGGL(fos::gemv_pair_resident_kernel<fos::bf16_t>, dim3(1), dim3(fos::RS_THREADS), 0, p->stream,
+                         (const fos::bf16_t*)p->A, p->lda, p->b, (int)p->m, (int)p->n, y, alpha2, grad, rr_out);
+    LAUNCH_CHECK();
+    return FOS_OK;
+  }
   YSource ys{nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, y};
   int n_rr = 0, rc;
   if ((rc = launch_pass(p, ys, p->b, true, &n_rr))) return rc;

@@ -338,6 +338,66 @@ __global__ __launch_bounds__(RS_THREADS) void fista_resident_kernel(const T* __r
   }
 }
 
+// One gradient of a small problem in one launch, all in fp64 on the fp32-stored A (L-BFGS fg, lbfgs.py:43-54):
+// grad = A^T (A y - b) + alpha2 y (rounded to fp32 once, on output), *rr_out = ||A y - b||^2.  Three launches of the
+// streaming path (fp32 pass, slab reduce, +alpha2 y) become one, and the line search of L-BFGS - which compares
+// objective values that differ in the 7th digit near the solution - sees a float64-accurate f and grad.
+template <typename T>
+__global__ __launch_bounds__(RS_THREADS) void gemv_pair_resident_kernel(const T* __restrict__ A, int64_t lda,
+                                                                       const float* __restrict__ b, int m, int n,
+                                                                       const double* __restrict__ y, double alpha2,
+                                                                       float* __restrict__ grad, double* __restrict__ rr_out) {
+  __shared__ double y_s[RS_MAX_N];
+  __shared__ double red[RS_WAVES][RS_CHUNK + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < n) y_s[tid] = y[tid];
+  __syncthreads();
+  constexpr int RPT = (RS_MAX_M + RS_THREADS - 1) / RS_THREADS;
+  double r_loc[RPT], rr = 0.0;
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int row = tid + q * RS_THREADS;
+    double acc = 0.0;
+    if (row < m) {
+      const T* ar = A + (int64_t)row * lda;
+      for (int j = 0; j < n; ++j) acc += (double)elem_to_float<T>(ar[j]) * y_s[j];
+      if (b != nullptr) acc -= (double)b[row];
+    }
+    r_loc[q] = acc;
+    rr += acc * acc;
+  }
+  for (int c0 = 0; c0 < n; c0 += RS_CHUNK) {
+    double v[RS_CHUNK + 1];
+#pragma unroll
+    for (int c = 0; c <= RS_CHUNK; ++c) v[c] = 0.0;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int row = tid + q * RS_THREADS;
+      if (row < m) {
+        const T* ar = A + (int64_t)row * lda + c0;                       // second touch: L1 / L2 hits
+#pragma unroll
+        for (int c = 0; c < RS_CHUNK; ++c)
+          if (c0 + c < n) v[c] += (double)elem_to_float<T>(ar[c]) * r_loc[q];
+      }
+    }
+    v[RS_CHUNK] = rr;
+    wave_sum_n(v);
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c <= RS_CHUNK; ++c) red[wave][c] = v[c];
+    }
+    __syncthreads();
+    if (tid <= RS_CHUNK && (tid == RS_CHUNK ? c0 == 0 : c0 + tid < n)) {
+      double tot = 0.0;
+#pragma unroll
+      for (int w = 0; w < RS_WAVES; ++w) tot += red[w][tid];
+      if (tid == RS_CHUNK) { if (rr_out != nullptr) *rr_out = tot; }
+      else grad[c0 + tid] = (float)(tot + alpha2 * y_s[c0 + tid]);
+    }
+    __syncthreads();
+  }
+}
+
 // Power iteration (iterative_solvers.py:45-60) in the same resident form: v normalised start vector in, L sequence out.
 // Lout: n_iter doubles (L after each step); iters_used: index of the step at which |L - prev| < tol fired (+1), or n_iter.
 template <typename T>
