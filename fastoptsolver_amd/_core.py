@@ -89,7 +89,8 @@ class Problem:
         esz = 2 if want_bf16 else 4
         fused_ok = borrowable and n % gran == 0 and (At.stride(0) % gran == 0 or m == 1) and At.data_ptr() % 16 == 0
         if pad is None:
-            pad = (not fused_ok) and m * n >= (1 << 24)
+            # n <= 64 runs the row-per-thread kernel, which takes ragged / misaligned rows as they are
+            pad = (not fused_ok) and m * n >= (1 << 24) and n > 64
         n_dev = n
         if pad and not fused_ok:
             n_dev = (n + gran - 1) // gran * gran
@@ -152,6 +153,7 @@ class Problem:
         flags = plan["nontemporal"]
         plan["nontemporal"] = flags & 1
         plan["resident"] = (flags >> 1) & 1       # small problem: whole runs execute in one LDS-resident launch
+        plan["tall"] = (flags >> 2) & 1           # n <= 64: row-per-thread single pass (any alignment)
         return plan
 
     def tune(self, threads, chunks, rows, workgroups=0):

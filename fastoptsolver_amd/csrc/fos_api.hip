@@ -13,6 +13,7 @@
 #include "batch_trial.hpp"
 #include "gemv_multi.hpp"
 #include "gemv_pair.hpp"
+#include "gemv_tall.hpp"
 #include "lbfgs_kernels.hpp"
 #include "reduce_update.hpp"
 #include "resident.hpp"
@@ -91,6 +92,44 @@ const MenuEntry* default_entry(int dtype, int64_t n) {
   return nullptr;
 }
 
+// ---- tall-skinny entries (gemv_tall.hpp): n <= 64, any m / lda; one entry per column capacity and load form --------
+template <typename T, int NC, int LOAD, bool WITH_G, bool DUAL>
+void tall_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, float* slabs,
+                 double* rr_part, double* rr2_part, int nwg, hipStream_t st) {
+  hipLaunchKernelGGL((fos::gemv_tall_kernel<T, NC, LOAD, WITH_G, DUAL>), dim3(nwg), dim3(fos::TL_THREADS), 0, st,
+                     reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part, rr2_part);
+}
+#define TALL(DT, T, NC, LD) \
+  { DT, fos::TL_THREADS, 0, 0, tall_launch<T, NC, LD, true, false>, tall_launch<T, NC, LD, false, false>, \
+    tall_launch<T, NC, LD, true, true> }
+// 64 columns: y, the row and the fp64 accumulators already fill the register file; no DUAL form (callers then take
+// the history objective from a residual pass of its own)
+#define TALL_ND(DT, T, NC, LD) \
+  { DT, fos::TL_THREADS, 0, 0, tall_launch<T, NC, LD, true, false>, tall_launch<T, NC, LD, false, false>, nullptr }
+#define TALL_ROW(DT, T, NC) { TALL(DT, T, NC, fos::TL_DIRECT), TALL(DT, T, NC, fos::TL_VEC), TALL(DT, T, NC, fos::TL_STAGE) }
+const MenuEntry kTallF32[4][3] = {
+    TALL_ROW(FOS_F32, float, 8), TALL_ROW(FOS_F32, float, 16), TALL_ROW(FOS_F32, float, 32),
+    {TALL_ND(FOS_F32, float, 64, fos::TL_DIRECT), TALL_ND(FOS_F32, float, 64, fos::TL_VEC),
+     TALL_ND(FOS_F32, float, 64, fos::TL_DIRECT)}};
+const MenuEntry kTallBf16[4][2] = {
+    {TALL(FOS_BF16, fos::bf16_t, 8, fos::TL_DIRECT), TALL(FOS_BF16, fos::bf16_t, 8, fos::TL_STAGE)},
+    {TALL(FOS_BF16, fos::bf16_t, 16, fos::TL_DIRECT), TALL(FOS_BF16, fos::bf16_t, 16, fos::TL_STAGE)},
+    {TALL(FOS_BF16, fos::bf16_t, 32, fos::TL_DIRECT), TALL(FOS_BF16, fos::bf16_t, 32, fos::TL_STAGE)},
+    {TALL_ND(FOS_BF16, fos::bf16_t, 64, fos::TL_DIRECT), TALL_ND(FOS_BF16, fos::bf16_t, 64, fos::TL_DIRECT)}};
+#undef TALL
+#undef TALL_ND
+#undef TALL_ROW
+// load form: 16-byte row loads when the layout allows, LDS staging for contiguous ragged matrices, scalar loads otherwise
+const MenuEntry* tall_entry(int dtype, int64_t n, int64_t lda, const void* A) {
+  const int idx = n <= 8 ? 0 : n <= 16 ? 1 : n <= 32 ? 2 : 3;
+  const bool contiguous = (lda == n);
+  if (dtype == FOS_F32) {
+    const bool vec = n % 4 == 0 && lda % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15u) == 0;
+    return &kTallF32[idx][vec ? fos::TL_VEC : (contiguous ? fos::TL_STAGE : fos::TL_DIRECT)];
+  }
+  return &kTallBf16[idx][contiguous ? 1 : 0];
+}
+
 int grid_1d(int64_t n, int per_block, int cap) {
   int64_t g = (n + per_block - 1) / per_block;
   return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
@@ -108,6 +147,8 @@ struct fos_problem {
   // plan
   int path = 0;                      // 0 fused, 1 two-pass fallback
   bool resident = false;             // small enough for the single-launch LDS-resident loop (resident.hpp)
+  bool tall = false;                 // n <= 64: row-per-thread single pass (gemv_tall.hpp); no alignment requirements
+  int64_t slab_stride = 0;           // floats between slab rows (0 = n); the tall pass pads rows to a multiple of 4
   const MenuEntry* entry = nullptr;
   int nwg = 0;                       // workgroups of the fused kernel
   int nslabs = 0;
@@ -174,6 +215,19 @@ void plan_fused(fos_problem* p, const MenuEntry* e, int nwg_hint) {
   p->nslabs = p->nwg;
 }
 
+// Row-per-thread pass: every thread gets at least 4 rows when m allows, at most 4 workgroups per CU.
+void plan_tall(fos_problem* p, const MenuEntry* e) {
+  p->entry = e;
+  p->path = 0;
+  p->tall = true;
+  p->slab_stride = fos::tall_slab_stride((int)p->n);
+  p->vec4 = true;                    // padded slab rows: the float4 epilogues serve ragged n as well
+  int64_t nwg = std::max<int64_t>(1, std::min<int64_t>(4 * (int64_t)p->ncu, p->m / (4 * fos::TL_THREADS)));
+  p->rows_per_wg = (p->m + nwg - 1) / nwg;
+  p->nwg = (int)((p->m + p->rows_per_wg - 1) / p->rows_per_wg);
+  p->nslabs = p->nwg;
+}
+
 void plan_fallback(fos_problem* p) {
   p->entry = nullptr;
   p->path = 1;
@@ -190,7 +244,7 @@ int ensure_workspace(fos_problem* p) {
     if (p->slabs) (void)hipFree(p->slabs);
     p->slabs = nullptr;
     p->slab_cap = 0;
-    HIP_TRY(hipMalloc(&p->slabs, (size_t)need_slabs * p->n * sizeof(float)));
+    HIP_TRY(hipMalloc(&p->slabs, (size_t)need_slabs * (p->slab_stride ? p->slab_stride : p->n) * sizeof(float)));
     p->slab_cap = need_slabs;
   }
   const int need_rr = std::max(p->nwg, std::max(p->resid_grid, 1));
@@ -287,7 +341,7 @@ int launch_slab_reduce(fos_problem* p, int n_rr, float* gbuf, double* rr_out, co
   const int grid = (int)((p->n + fos::RCOLS - 1) / fos::RCOLS);
   if (p->vec4)
     hipLaunchKernelGGL(fos::slab_reduce_kernel<true>, dim3(grid), dim3(256), 0, p->stream, p->slabs, p->nslabs,
-                       (int)p->n, p->rr_part, n_rr, gbuf, rr_out, stopped);
+                       (int)p->n, p->rr_part, n_rr, gbuf, rr_out, stopped, p->slab_stride);
   else
     hipLaunchKernelGGL(fos::slab_reduce_kernel<false>, dim3(grid), dim3(256), 0, p->stream, p->slabs, p->nslabs,
                        (int)p->n, p->rr_part, n_rr, gbuf, rr_out, stopped);
@@ -376,7 +430,7 @@ MultiLaunch find_multi(int64_t n, int nv) {
   return nullptr;
 }
 
-bool batch_supported(const fos_problem* p) { return p->path == 0; }   // fp32: f32 MFMA; bf16: 3-term bf16 MFMA
+bool batch_supported(const fos_problem* p) { return p->path == 0 && !p->tall; }   // fp32: f32 MFMA; bf16: 3-term bf16 MFMA
 
 // A caller vector the fused prologue can read with 16-byte loads.
 int aligned_vec(fos_problem* p, const float* v, const float** out) {
@@ -416,7 +470,10 @@ int fos_problem_create(fos_problem** out, const void* A, int64_t m, int64_t n, i
   const int epc = epc_of(a_dtype);
   const bool vec_ok = (n % epc == 0) && (lda % epc == 0) && ((reinterpret_cast<uintptr_t>(A) & 15u) == 0);
   const MenuEntry* e = vec_ok ? default_entry(a_dtype, n) : nullptr;
-  if (e) plan_fused(p, e, 0); else plan_fallback(p);
+  if (n <= fos::TL_MAX_N && getenv("FOS_NO_TALL") == nullptr)
+    plan_tall(p, tall_entry(a_dtype, n, lda, A));
+  else if (e) plan_fused(p, e, 0);
+  else plan_fallback(p);
   int rc = ensure_workspace(p);
   if (rc == FOS_OK) {
     hipError_t he = hipMalloc(&p->gbuf_own, (size_t)(n + 4) * sizeof(float));
@@ -472,14 +529,15 @@ int fos_problem_plan(const fos_problem* p, int32_t plan[8]) {
   plan[3] = p->entry ? p->entry->r : 0;
   plan[4] = p->nwg;
   plan[5] = p->nslabs;
-  plan[6] = (p->path == 0 ? 1 : 0) | (p->resident ? 2 : 0);
+  plan[6] = (p->path == 0 ? 1 : 0) | (p->resident ? 2 : 0) | (p->tall ? 4 : 0);
   plan[7] = p->ncu;
   return FOS_OK;
 }
 
 int fos_problem_tune(fos_problem* p, int threads, int chunks, int rows, int workgroups) {
   if (!p) return fail(FOS_ERR_ARG, "fos_problem_tune: null");
-  if (p->path != 0) return fail(FOS_ERR_UNSUPPORTED, "fos_problem_tune: problem runs the two-pass fallback");
+  if (p->path != 0 || p->tall)
+    return fail(FOS_ERR_UNSUPPORTED, "fos_problem_tune: only the streaming single-pass kernel has a geometry menu");
   const MenuEntry* e = find_entry(p->dtype, threads, chunks, rows);
   if (!e || (int64_t)e->threads * e->k * epc_of(p->dtype) < p->n)
     return fail(FOS_ERR_UNSUPPORTED, "fos_problem_tune: geometry not instantiated or too narrow for n");
@@ -758,6 +816,7 @@ static void launch_update_from_slabs(fos_fista* f, double* part, int host_beta, 
                                      const float* slabs = nullptr, int64_t slab_stride = 0) {
   fos_problem* p = f->p;
   if (slabs == nullptr) slabs = p->slabs;
+  if (slab_stride == 0) slab_stride = p->slab_stride;
   if (p->vec4)
     hipLaunchKernelGGL((fos::fista_update_kernel<true, true>), dim3(f->nupd), dim3(256), 0, p->stream, slabs,
                        p->nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
@@ -968,7 +1027,7 @@ int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters) {
     if (!fs[v] || fs[v]->p != fs[0]->p) return fail(FOS_ERR_ARG, "fos_fista_run_multi: handles must share one problem");
   if (nv == 1) return fos_fista_run(fs[0], iters);
   fos_problem* p = fs[0]->p;
-  MultiLaunch fn = (p->path == 0 && p->dtype == FOS_F32) ? find_multi(p->n, nv) : nullptr;
+  MultiLaunch fn = (p->path == 0 && !p->tall && p->dtype == FOS_F32) ? find_multi(p->n, nv) : nullptr;
   for (int v = 0; v < nv && fn; ++v)
     if (!plain_run(fs[v])) fn = nullptr;
   if (!fn) return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_multi: no multi-vector kernel for this shape / configuration");

@@ -1,0 +1,136 @@
+// Tall-skinny single-pass GEMV pair: n <= 64 columns, any m, any lda >= n, ragged n welcome.
+//
+// The streaming kernel (gemv_pair.hpp) gives a whole row to a workgroup: with rows of a few dozen bytes - regression
+// data with many samples and few features, the reference's own domain (its generator is m x 5) - nearly every lane
+// idles (1,000,000 x 5 ran at 0.1 % of the HBM roofline, 1.7 ms per iteration).  Here every THREAD owns whole rows:
+// lane l of a wave reads row base+l, so a wave's loads cover 64 consecutive rows = one contiguous block of memory
+// (A is row-major), the dot with y and the rank-1 update of the gradient happen in that thread's registers, and one
+// block reduction per workgroup ends the pass.  y (and x_k for DUAL) sits in LDS as doubles (broadcast reads); the
+// row dots, ||r||^2 and the gradient accumulators are fp64 (these problems are the ill-conditioned ones, cond 1e9 for
+// the unstandardised Boston features), the slab written per workgroup is fp32 like every other path.
+// Output contract = gemv_pair_kernel except for the slab row stride: slabs[wg][tall_slab_stride(n)] (zero padded),
+// rr_part[wg], rr2_part[wg] (DUAL), rows [wg*rows_per_wg, ...).
+#pragma once
+#include "gemv_pair.hpp"
+
+namespace fos {
+
+constexpr int TL_THREADS = 256;
+constexpr int TL_MAX_N = 64;
+__host__ __device__ inline int tall_slab_stride(int n) { return (n + 3) & ~3; }
+
+// NC: compile-time column capacity (8/16/32/64; columns beyond n are zero).  LOAD: how a thread gets its row -
+//   TL_DIRECT  scalar loads straight from global (any lda; a wave's 64 rows share cache lines, so HBM traffic stays 1x,
+//              but every instruction touches all of them: 2.6 % of the roofline at n = 5)
+//   TL_VEC     16-byte loads (fp32, n % 4 == 0, lda % 4 == 0, A 16-byte aligned)
+//   TL_STAGE   contiguous matrix (lda == n), ragged n: the workgroup copies its 256 x n block of A - one contiguous
+//              span of memory - into LDS with fully coalesced loads, and each thread then reads its row from LDS
+//              (stride n words: conflict-free for odd n); NC <= 32 (LDS budget)
+enum : int { TL_DIRECT = 0, TL_VEC = 1, TL_STAGE = 2 };
+template <typename T, int NC, int LOAD, bool WITH_G, bool DUAL>
+__global__ __launch_bounds__(TL_THREADS) void gemv_tall_kernel(const T* __restrict__ A, int64_t lda,
+                                                              const float* __restrict__ b, int64_t m, int n, YSource ys,
+                                                              int64_t rows_per_wg, float* __restrict__ slabs,
+                                                              double* __restrict__ rr_part, double* __restrict__ rr2_part) {
+  constexpr int NW = TL_THREADS / 64;
+  constexpr bool VEC = (LOAD == TL_VEC), STAGE = (LOAD == TL_STAGE);
+  __shared__ float tile_s[STAGE ? TL_THREADS * NC : 1];
+  __shared__ double y_s[NC];
+  __shared__ double x_s[DUAL ? NC : 1];
+  __shared__ double red[NW][8];
+  if (ys.stopped != nullptr && *ys.stopped != 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double beta = source_beta(ys);
+  const int sstride = tall_slab_stride(n);
+  if (tid < NC) {
+    y_s[tid] = tid < n ? source_y(ys, tid, beta) : 0.0;
+    if constexpr (DUAL) x_s[tid] = tid < n ? ys.x_cur[tid] : 0.0;
+  }
+  __syncthreads();
+
+  double g[WITH_G ? NC : 1];
+#pragma unroll
+  for (int j = 0; j < (WITH_G ? NC : 1); ++j) g[j] = 0.0;
+  double rr = 0.0, rr2 = 0.0;
+  const int64_t row_lo = (int64_t)blockIdx.x * rows_per_wg;
+  int64_t row_hi = row_lo + rows_per_wg;
+  if (row_hi > m) row_hi = m;
+  for (int64_t row0 = row_lo; row0 < row_hi; row0 += TL_THREADS) {        // uniform loop: TL_STAGE needs the barriers
+    const int64_t row = row0 + tid;
+    if constexpr (STAGE) {
+      const int64_t left = row_hi - row0;
+      const int count = (int)(left < TL_THREADS ? left : TL_THREADS) * n;
+      const T* src = A + row0 * (int64_t)n;                              // lda == n: the block is one contiguous span
+      __syncthreads();                                                   // the previous block has been consumed
+#pragma unroll
+      for (int u = 0; u < NC; ++u) {
+        const int i = u * TL_THREADS + tid;
+        if (i < count) tile_s[i] = elem_to_float<T>(src[i]);
+      }
+      __syncthreads();
+    }
+    if (row < row_hi) {
+      float a[NC];
+      if constexpr (STAGE) {
+        const float* ar = tile_s + tid * n;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) a[j] = j < n ? ar[j] : 0.f;
+      } else if constexpr (VEC) {
+        const T* ar = A + row * lda;
+#pragma unroll
+        for (int c = 0; c < NC / 4; ++c) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (4 * c < n) v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ar) + c);
+          a[4 * c] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
+        }
+      } else {
+        const T* ar = A + row * lda;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) a[j] = j < n ? elem_to_float<T>(ar[j]) : 0.f;
+      }
+      const double bi = b != nullptr ? (double)b[row] : 0.0;
+      double acc = -bi, acc2 = -bi;
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        acc += (double)a[j] * y_s[j];
+        if constexpr (DUAL) acc2 += (double)a[j] * x_s[j];
+      }
+      rr += acc * acc;
+      if constexpr (DUAL) rr2 += acc2 * acc2;
+      if constexpr (WITH_G) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) g[j] += (double)a[j] * acc;
+      }
+    }
+  }
+
+  // ---- one block reduction per workgroup: 8 values at a time through the DPP ladder, 4 wave partials through LDS ----
+  auto block_reduce8 = [&](double (&v)[8], auto&& sink) {
+    wave_sum_n(v);
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) red[wave][c] = v[c];
+    }
+    __syncthreads();
+    if (tid < 8) sink(tid, (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+    __syncthreads();
+  };
+  if constexpr (WITH_G) {
+#pragma unroll
+    for (int c0 = 0; c0 < NC; c0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = g[c0 + c];
+      block_reduce8(v, [&](int c, double tot) {      // slab rows are padded to a multiple of 4 floats (zeros): the
+        if (c0 + c < sstride) slabs[(int64_t)blockIdx.x * sstride + c0 + c] = (float)tot;   // float4 epilogues take any n
+      });
+    }
+  }
+  double tail[8] = {rr, rr2, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  block_reduce8(tail, [&](int c, double tot) {
+    if (c == 0) rr_part[blockIdx.x] = tot;
+    if (DUAL && c == 1) rr2_part[blockIdx.x] = tot;
+  });
+}
+
+}  // namespace fos

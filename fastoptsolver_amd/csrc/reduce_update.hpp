@@ -132,14 +132,20 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int nslabs, int n,
                                                          const double* __restrict__ rr_part, int n_rr,
                                                          float* __restrict__ gbuf, double* __restrict__ rr_out,
-                                                         const int* stopped) {
+                                                         const int* stopped, int64_t slab_stride = 0) {
   if (stopped != nullptr && *stopped != 0) return;
   __shared__ f32x4 lds[RG][RQ];
   const int col0 = blockIdx.x * RCOLS;
   if constexpr (VEC) {
-    const f32x4 tot = reduce_slab_block(slabs, nslabs, n, col0, lds);
+    const f32x4 tot = reduce_slab_block(slabs, nslabs, n, col0, lds, slab_stride);
     const int q = threadIdx.x % RQ, grp = threadIdx.x / RQ;
-    if (grp == 0 && col0 + 4 * q < n) *reinterpret_cast<f32x4*>(gbuf + col0 + 4 * q) = tot;
+    const int col = col0 + 4 * q;
+    if (grp == 0 && col + 3 < n) *reinterpret_cast<f32x4*>(gbuf + col) = tot;
+    else if (grp == 0 && col < n) {                  // ragged n: gbuf[n] belongs to the rr fold below
+      gbuf[col] = tot.x;
+      if (col + 1 < n) gbuf[col + 1] = tot.y;
+      if (col + 2 < n) gbuf[col + 2] = tot.z;
+    }
   } else {
     if (threadIdx.x < RCOLS) {
       const int col = col0 + threadIdx.x;
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256) void fista_update_kernel(const float* __restri
       const f32x4 t = *reinterpret_cast<const f32x4*>(gbuf + col);
       g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w;
     }
-    cnt = owner ? 4 : 0;
+    cnt = owner ? (n - col < 4 ? n - col : 4) : 0;      // ragged n (padded slab rows): the last quad is partial
   } else {
     col = col0 + threadIdx.x;
     owner = (threadIdx.x < RCOLS) && (col < n);

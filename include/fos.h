@@ -74,7 +74,8 @@ int fos_problem_create(fos_problem** out, const void* A, int64_t m, int64_t n, i
 int fos_problem_destroy(fos_problem* p);
 /* plan[0..7] = {path (0 fused single pass, 1 two-pass fallback), threads, chunks/thread, rows/step,
  *               workgroups, slabs, flags (bit 0: non-temporal loads; bit 1: small enough for the single-launch
- *               LDS-resident loop that fos_fista_run / _run_history / fos_power_iter then use), CUs} */
+ *               LDS-resident loop that fos_fista_run / _run_history / fos_power_iter then use; bit 2: n <= 64, the
+ *               single pass is the row-per-thread kernel, which has no alignment requirements), CUs} */
 int fos_problem_plan(const fos_problem* p, int32_t plan[8]);
 /* Benchmark/tuning override of the fused-kernel geometry; returns FOS_ERR_UNSUPPORTED if not instantiated. */
 int fos_problem_tune(fos_problem* p, int threads, int chunks, int rows, int workgroups);

@@ -218,12 +218,14 @@ def test_fista_family_vs_reference_goldens(fos, tag):
 
 
 def test_boston_config1(fos):
-    """BASELINE config 1: Boston-like Lasso through the device path (two-pass fallback: n = 5)."""
+    """BASELINE config 1: Boston-like Lasso through the device path (n = 5: LDS-resident loop; the split entry points
+    and larger m take the row-per-thread single pass)."""
     fx = _data.load("boston")
     A, b = fx["boston/A"], fx["boston/b"]
     np.random.seed(0)
     x, h = fos.fista(A, b, "lasso", 1.0, 0.0, max_iter=500, return_history=True)
-    assert fos.prepare(A, b).plan()["path"] == 1
+    plan = fos.prepare(A, b).plan()
+    assert plan["resident"] == 1 and plan["tall"] == 1 and plan["path"] == 0
     for k, xr in zip(fx["boston/fista_lasso/ks"], fx["boston/fista_lasso/xs"]):
         assert _data.rel(h["x"][k], xr) < TOL, int(k)
     assert np.allclose(h["obj"], fx["boston/fista_lasso/obj"], rtol=TOL)
@@ -463,8 +465,9 @@ def test_ista_with_arbitrary_torch_closures(fos):
 
 @pytest.mark.parametrize("m,n,nv", [(64, 16, 16), (1000, 512, 5), (777, 132, 3), (4099, 8192, 16), (130, 16384, 9), (1, 4, 1),
                                     (32845, 260, 7)])          # the last one is tall enough for the 128-row tile
-def test_residual_batch_mfma_vs_oracle(fos, m, n, nv):
+def test_residual_batch_mfma_vs_oracle(fos, m, n, nv, monkeypatch):
     """The batched (matrix-core) residual kernel: ||A X_j - b||^2 for up to 16 vectors in one pass."""
+    monkeypatch.setenv("FOS_NO_TALL", "1")      # n <= 64 would plan the row-per-thread pass, which has no MFMA batch
     rng = np.random.default_rng(m + n + nv)
     A = rng.standard_normal((m, n)).astype(np.float32)
     b = rng.standard_normal(m).astype(np.float32)
@@ -480,9 +483,10 @@ def test_residual_batch_mfma_vs_oracle(fos, m, n, nv):
 
 @pytest.mark.parametrize("m,n,nv", [(64, 16, 16), (1000, 512, 5), (777, 136, 3), (4099, 8192, 16), (130, 16384, 9), (1, 8, 1),
                                     (32845, 264, 7)])          # the last one is tall enough for the 128-row tile
-def test_residual_batch_mfma_bf16_vs_oracle(fos, m, n, nv):
+def test_residual_batch_mfma_bf16_vs_oracle(fos, m, n, nv, monkeypatch):
     """bf16 A on v_mfma_f32_16x16x32_bf16: the candidates are split into three bf16 terms (24 mantissa bits), so the
     result keeps the fp32 tolerance against the float64 product with the bf16-ROUNDED A."""
+    monkeypatch.setenv("FOS_NO_TALL", "1")
     rng = np.random.default_rng(m + n + nv)
     A16 = torch.as_tensor(rng.standard_normal((m, n)).astype(np.float32)).to(torch.bfloat16)
     Aq = A16.to(torch.float64).numpy()
@@ -779,3 +783,56 @@ def test_resident_loop_with_bf16_storage(fos):
         x_ref, h_ref = orc.fista(Aq, b, "elasticnet", 0.05 * lam, 0.5, max_iter=40, L=L, return_history=True, **kw)
         assert _data.rel(x.cpu().numpy() if torch.is_tensor(x) else x, x_ref) < TOL, kw
         assert np.allclose(h["obj"], h_ref["obj"], rtol=TOL), kw
+
+
+# --------------------------------------------------------------------------------------------------
+# tall-skinny single pass (n <= 64, row per thread): regression shapes with many samples and few features
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,kind", [(20000, 5, "f32"), (20001, 7, "f32"), (70000, 8, "f32"), (33333, 16, "f32"),
+                                      (9000, 33, "f32"), (12345, 64, "f32"), (5000, 32, "strided"), (6000, 12, "bf16"),
+                                      (200, 64, "f32"), (1, 40, "f32")])
+def test_tall_skinny_gemv_pair(fos, m, n, kind):
+    rng = np.random.default_rng(m + n)
+    A = rng.standard_normal((m, n)).astype(np.float32)
+    b = rng.standard_normal(m).astype(np.float32)
+    y = rng.standard_normal(n).astype(np.float32)
+    if kind == "strided":                                   # rows 40 floats apart: lda > n, borrowed as it is
+        big = torch.as_tensor(np.hstack([A, np.zeros((m, 8), np.float32)])).cuda()
+        At = big[:, :n]
+    elif kind == "bf16":
+        At = torch.as_tensor(A).to(torch.bfloat16).cuda()
+        A = At.float().cpu().numpy()
+    else:
+        At = torch.as_tensor(A).cuda()
+    prob = fos.prepare(At, b)
+    plan = prob.plan()
+    assert plan["tall"] == 1 and plan["path"] == 0 and prob.n_dev == n
+    g = prob.gemv_pair(_dev(y), alpha2=0.3).cpu().numpy()
+    g_ref, rr_ref = orc.gram_gradient(A.astype(np.float64), y.astype(np.float64), b.astype(np.float64), 0.3)
+    assert _data.rel(g, g_ref) < 1e-6, (m, n, kind)
+    rr, x2, x1 = prob.residual_objective(_dev(y))
+    assert rr == pytest.approx(rr_ref, rel=1e-6) and x1 == pytest.approx(np.abs(y.astype(np.float64)).sum(), rel=1e-6)
+    # deterministic: bit-identical across launches
+    assert torch.equal(prob.gemv_pair(_dev(y), alpha2=0.3), prob.gemv_pair(_dev(y), alpha2=0.3))
+
+
+def test_tall_skinny_solvers_on_unstandardised_features(fos):
+    """50000 x 5 Boston-like data (cond(A^T A) ~ 1e9): every solver family through the row-per-thread pass."""
+    from fastoptsolver_amd.easy_boston_data import generate_correlated_boston_like_data
+    A, b, _ = generate_correlated_boston_like_data(m=50000, seed=7)
+    prob = fos.prepare(A, b)
+    assert prob.plan()["tall"] == 1 and prob.plan()["resident"] == 0
+    np.random.seed(0)
+    L = fos.estimate_lipschitz(prob)
+    np.random.seed(0)
+    assert L == pytest.approx(orc.estimate_lipschitz(A, v0=np.random.randn(5)), rel=1e-6)
+    for kw in (dict(), dict(adaptive_restart=True), dict(backtracking=True, t_init_factor=2.0)):
+        x, h = fos.fista(prob, None, "lasso", 1.0, 0.0, max_iter=120, L=L, return_history=True, **kw)
+        x_ref, h_ref = orc.fista(A, b, "lasso", 1.0, 0.0, max_iter=120, L=L, return_history=True, **kw)
+        assert _data.rel(x, x_ref) < TOL, kw
+        assert np.allclose(h["obj"], h_ref["obj"], rtol=TOL), kw
+    x = fos.fista_delta(prob, None, "elasticnet", 1.0, 0.5, 3.0, max_iter=120, L=L)
+    assert _data.rel(x, orc.fista_delta(A, b, "elasticnet", 1.0, 0.5, 3.0, max_iter=120, L=L)) < TOL
+    s = fos.LBFGSSolver("ridge", 0.0, 0.5).fit(prob, None)
+    s_ref = orc.LBFGSSolver("ridge", 0.0, 0.5).fit(A, b)
+    assert _data.rel(s.x_, s_ref.x_) < 1e-4 and s.final_obj_ == pytest.approx(s_ref.final_obj_, rel=1e-6)
