@@ -34,7 +34,7 @@ __global__ __launch_bounds__(TL_THREADS) void gemv_tall_kernel(const T* __restri
                                                               double* __restrict__ rr_part, double* __restrict__ rr2_part) {
   constexpr int NW = TL_THREADS / 64;
   constexpr bool VEC = (LOAD == TL_VEC), STAGE = (LOAD == TL_STAGE);
-  __shared__ float tile_s[STAGE ? TL_THREADS * NC : 1];
+  __shared__ float tile_s[STAGE ? (NC <= 16 ? 2 : 1) * TL_THREADS * NC : 1];
   __shared__ double y_s[NC];
   __shared__ double x_s[DUAL ? NC : 1];
   __shared__ double red[NW][8];
@@ -55,51 +55,61 @@ __global__ __launch_bounds__(TL_THREADS) void gemv_tall_kernel(const T* __restri
   const int64_t row_lo = (int64_t)blockIdx.x * rows_per_wg;
   int64_t row_hi = row_lo + rows_per_wg;
   if (row_hi > m) row_hi = m;
-  for (int64_t row0 = row_lo; row0 < row_hi; row0 += TL_THREADS) {        // uniform loop: TL_STAGE needs the barriers
-    const int64_t row = row0 + tid;
+  // RPI rows per thread per loop trip: the loads of all of them are issued before the first is consumed (a thread has
+  // no other memory-level parallelism than its own rows); 2 where the registers allow (NC <= 16).
+  constexpr int RPI = NC <= 16 ? 2 : 1;
+  constexpr int BLOCK_ROWS = RPI * TL_THREADS;
+  for (int64_t row0 = row_lo; row0 < row_hi; row0 += BLOCK_ROWS) {          // uniform loop: TL_STAGE needs the barriers
     if constexpr (STAGE) {
       const int64_t left = row_hi - row0;
-      const int count = (int)(left < TL_THREADS ? left : TL_THREADS) * n;
+      const int count = (int)(left < BLOCK_ROWS ? left : BLOCK_ROWS) * n;
       const T* src = A + row0 * (int64_t)n;                              // lda == n: the block is one contiguous span
       __syncthreads();                                                   // the previous block has been consumed
 #pragma unroll
-      for (int u = 0; u < NC; ++u) {
+      for (int u = 0; u < NC * RPI; ++u) {
         const int i = u * TL_THREADS + tid;
         if (i < count) tile_s[i] = elem_to_float<T>(src[i]);
       }
       __syncthreads();
     }
-    if (row < row_hi) {
-      float a[NC];
-      if constexpr (STAGE) {
-        const float* ar = tile_s + tid * n;
+    float a[RPI][NC];
+    double bi[RPI];
 #pragma unroll
-        for (int j = 0; j < NC; ++j) a[j] = j < n ? ar[j] : 0.f;
+    for (int u = 0; u < RPI; ++u) {
+      const int64_t row = row0 + u * TL_THREADS + tid;
+      const bool in = row < row_hi;
+      bi[u] = (in && b != nullptr) ? (double)b[row] : 0.0;
+      if constexpr (STAGE) {
+        const float* ar = tile_s + (u * TL_THREADS + tid) * n;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) a[u][j] = (in && j < n) ? ar[j] : 0.f;
       } else if constexpr (VEC) {
         const T* ar = A + row * lda;
 #pragma unroll
         for (int c = 0; c < NC / 4; ++c) {
           f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (4 * c < n) v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ar) + c);
-          a[4 * c] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
+          if (in && 4 * c < n) v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ar) + c);
+          a[u][4 * c] = v.x; a[u][4 * c + 1] = v.y; a[u][4 * c + 2] = v.z; a[u][4 * c + 3] = v.w;
         }
       } else {
         const T* ar = A + row * lda;
 #pragma unroll
-        for (int j = 0; j < NC; ++j) a[j] = j < n ? elem_to_float<T>(ar[j]) : 0.f;
+        for (int j = 0; j < NC; ++j) a[u][j] = (in && j < n) ? elem_to_float<T>(ar[j]) : 0.f;
       }
-      const double bi = b != nullptr ? (double)b[row] : 0.0;
-      double acc = -bi, acc2 = -bi;
+    }
+#pragma unroll
+    for (int u = 0; u < RPI; ++u) {            // rows beyond row_hi: a = 0, b = 0 -> r = 0, no contribution
+      double acc = -bi[u], acc2 = -bi[u];
 #pragma unroll
       for (int j = 0; j < NC; ++j) {
-        acc += (double)a[j] * y_s[j];
-        if constexpr (DUAL) acc2 += (double)a[j] * x_s[j];
+        acc += (double)a[u][j] * y_s[j];
+        if constexpr (DUAL) acc2 += (double)a[u][j] * x_s[j];
       }
       rr += acc * acc;
       if constexpr (DUAL) rr2 += acc2 * acc2;
       if constexpr (WITH_G) {
 #pragma unroll
-        for (int j = 0; j < NC; ++j) g[j] += (double)a[j] * acc;
+        for (int j = 0; j < NC; ++j) g[j] += (double)a[u][j] * acc;
       }
     }
   }

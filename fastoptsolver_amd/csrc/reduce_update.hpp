@@ -94,29 +94,36 @@ constexpr int RCOLS = RQ * 4;
 __device__ inline f32x4 reduce_slab_block(const float* __restrict__ slabs, int nslabs, int n, int col0,
                                           f32x4 (*lds)[RQ], int64_t stride = 0) {
   if (stride == 0) stride = n;       // distance between consecutive slabs (multi-lambda runs interleave NVEC sets)
-  const int q = threadIdx.x % RQ, grp = threadIdx.x / RQ;
+  // Quads in use by this workgroup: all RQ = 16 for a full 64-column block; for narrow problems (n <= 64 runs in ONE
+  // workgroup and may have ~1000 slabs to fold) the idle quads' threads become extra slab groups: nq quads x 256/nq
+  // groups.  nq is a power of two, so the lds rows of RQ float4 are simply re-indexed flat.
+  int quads = (n - col0 + 3) / 4;
+  int nq = RQ;
+  while (nq > 1 && (nq >> 1) >= quads) nq >>= 1;
+  const int ng = (RQ * RG) / nq;
+  const int q = threadIdx.x % nq, grp = threadIdx.x / nq;
   const int col = col0 + 4 * q;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (col < n) {
     const float* p = slabs + col;
     int s = grp;
-    for (; s + 3 * RG < nslabs; s += 4 * RG) {
+    for (; s + 3 * ng < nslabs; s += 4 * ng) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(p + (int64_t)s * stride);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(p + (int64_t)(s + RG) * stride);
-      const f32x4 c = *reinterpret_cast<const f32x4*>(p + (int64_t)(s + 2 * RG) * stride);
-      const f32x4 d = *reinterpret_cast<const f32x4*>(p + (int64_t)(s + 3 * RG) * stride);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(p + (int64_t)(s + ng) * stride);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(p + (int64_t)(s + 2 * ng) * stride);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(p + (int64_t)(s + 3 * ng) * stride);
       acc += a; acc += b; acc += c; acc += d;
     }
-    for (; s < nslabs; s += RG) acc += *reinterpret_cast<const f32x4*>(p + (int64_t)s * stride);
+    for (; s < nslabs; s += ng) acc += *reinterpret_cast<const f32x4*>(p + (int64_t)s * stride);
   }
-  lds[grp][q] = acc;
+  f32x4* flat = &lds[0][0];
+  flat[threadIdx.x] = acc;           // index grp * nq + q
   __syncthreads();
   f32x4 tot = {0.f, 0.f, 0.f, 0.f};
   if (grp == 0) {
-#pragma unroll
-    for (int g = 0; g < RG; ++g) tot += lds[g][q];
+    for (int g = 0; g < ng; ++g) tot += flat[g * nq + q];
   }
-  return tot;
+  return tot;                        // valid in the threads with threadIdx.x < nq (grp == 0), quad q = threadIdx.x
 }
 
 // Scalar-tail variant for n % 4 != 0 (fallback path): one column per thread-quad element.
