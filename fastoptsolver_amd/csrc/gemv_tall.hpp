@@ -88,7 +88,7 @@ __global__ __launch_bounds__(TL_THREADS) void gemv_tall_kernel(const T* __restri
 #pragma unroll
         for (int c = 0; c < NC / 4; ++c) {
           f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (in && 4 * c < n) v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ar) + c);
+          if (in && 4 * c < n) v = reinterpret_cast<const f32x4*>(ar)[c];   // cached: the 4 pieces of a line hit L1
           a[u][4 * c] = v.x; a[u][4 * c + 1] = v.y; a[u][4 * c + 2] = v.z; a[u][4 * c + 3] = v.w;
         }
       } else {
