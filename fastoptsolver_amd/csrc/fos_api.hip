@@ -72,7 +72,11 @@ struct MenuEntry {
   { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, 2, false>, fused_launch<T, TH, K, R, W, false, 2, false>, \
     fused_launch<T, TH, K, R, W, true, 2, true> }
 // Ordered by capacity (threads*k*EPC columns); first entry that fits n is the default.
+// The 64-thread entries give narrow rows (65..512 columns) one WAVE per row instead of a 256-thread workgroup whose
+// lanes would mostly idle (200000 x 256 ran at 18 % of the roofline on the 256-thread geometry); they are launched
+// with proportionally more workgroups (plan_fused).
 const MenuEntry kMenu[] = {
+    ENTRY_D(FOS_F32, float, 64, 1, 4, 2), ENTRY_D(FOS_F32, float, 64, 2, 4, 2),
     ENTRY_D(FOS_F32, float, 256, 1, 4, 2), ENTRY_D(FOS_F32, float, 256, 2, 4, 2), ENTRY_D(FOS_F32, float, 256, 4, 2, 2),
     ENTRY_NB(FOS_F32, float, 512, 4, 1, 2, 3),   ENTRY_DRAIN(FOS_F32, float, 1024, 4, 1, 4, 512, 8, 2),
     ENTRY_D(FOS_F32, float, 512, 8, 1, 2),  ENTRY(FOS_F32, float, 1024, 2, 2, 4),
@@ -207,7 +211,8 @@ void plan_fused(fos_problem* p, const MenuEntry* e, int nwg_hint) {
   p->entry = e;
   p->path = 0;
   int64_t m = p->m;
-  int nwg = nwg_hint > 0 ? nwg_hint : p->ncu;
+  // one workgroup per CU for the wide geometries (>= 256 threads); 8 single-wave workgroups per CU for the narrow ones
+  int nwg = nwg_hint > 0 ? nwg_hint : p->ncu * (e->threads >= 256 ? 1 : 512 / e->threads);
   const int64_t min_rows = 2 * (int64_t)e->r;
   if (m < (int64_t)nwg * min_rows) nwg = (int)std::max<int64_t>(1, m / min_rows);
   p->rows_per_wg = (m + nwg - 1) / nwg;

@@ -662,7 +662,7 @@ def test_fista_path_equals_one_by_one(fos, nlam):
     for (a1, a2), x in zip(alphas, xs):
         x_one = fos.fista(prob, None, "elasticnet", a1, a2, max_iter=40, L=L)
         x_ref = orc.fista(A, b, "elasticnet", a1, a2, max_iter=40, L=L)
-        assert _data.rel(x, x_one) < 1e-9, (a1, a2)          # same arithmetic, different kernel instantiation
+        assert _data.rel(x, x_one) < 1e-6, (a1, a2)          # same arithmetic, other geometry (summation order) of the pass
         assert _data.rel(x, x_ref) < TOL, (a1, a2)
     xd = fos.fista_path(prob, None, alphas[:2], max_iter=30, L=L, delta=3.0)
     assert _data.rel(xd[1], orc.fista_delta(A, b, "elasticnet", alphas[1][0], alphas[1][1], 3.0, max_iter=30, L=L)) < TOL
