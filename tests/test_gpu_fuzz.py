@@ -190,3 +190,26 @@ def test_random_backtracking(fos, seed):
         xk = h["x"][good if not delta else good - 1]         # fista's history starts with x0, fista_delta's with x1
         den = max(max(np.linalg.norm(v) for v in xs[:good]), 1e-12)
         assert np.linalg.norm(np.asarray(xk) - xs[good - 1]) / den < TOL, (seed, good, A.shape, a1, a2, eta, tf, delta)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FOS_FUZZ_SHAPE_SEEDS", "40"))))
+def test_random_shapes_and_layouts_gemv_pair(fos, seed):
+    """The single pass over A through whatever kernel the planner picks - resident / row-per-thread (n <= 64),
+    one-wave-per-row (65..512), wide streaming geometries, two-pass - on random shapes, row strides and alignments."""
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 31, 32, 33, 63, 64, 65, 100, 128, 255, 256, 260, 511, 512, 516, 700, 1024, 1500]))
+    m = int(rng.choice([1, 2, 7, 64, 255, 256, 257, 1000, 4096, 4097, 10000, 30001]))
+    pad = int(rng.choice([0, 0, 1, 3, 4, 8]))                 # extra floats between rows (lda = n + pad)
+    off = int(rng.choice([0, 0, 1, 4]))                       # start offset in floats (16-byte alignment or not)
+    flat = torch.randn(off + m * (n + pad) + 8, device="cuda")
+    At = flat[off: off + m * (n + pad)].view(m, n + pad)[:, :n]
+    A = At.cpu().numpy().astype(np.float64)
+    b = rng.standard_normal(m).astype(np.float32)
+    y = rng.standard_normal(n).astype(np.float32)
+    prob = fos.prepare(At, b)
+    g = prob.gemv_pair(torch.as_tensor(y).cuda(), alpha2=0.25).cpu().numpy()
+    g_ref, rr_ref = orc.gram_gradient(A, y.astype(np.float64), b.astype(np.float64), 0.25)
+    scale = max(np.linalg.norm(g_ref), 1e-6 * np.linalg.norm(A) * (np.linalg.norm(A @ y) + np.linalg.norm(b)))
+    assert np.linalg.norm(g - g_ref) / scale < 2e-6, (seed, m, n, pad, off, prob.plan())
+    rr = prob.residual_objective(torch.as_tensor(y).cuda())[0]
+    assert rr == pytest.approx(rr_ref, rel=5e-6, abs=1e-12), (seed, m, n, pad, off, prob.plan())
