@@ -103,6 +103,16 @@ void tall_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, Y
   hipLaunchKernelGGL((fos::gemv_tall_kernel<T, NC, LOAD, WITH_G, DUAL>), dim3(nwg), dim3(fos::TL_THREADS), 0, st,
                      reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part, rr2_part);
 }
+template <typename T, bool VEC, bool WITH_G, bool DUAL>
+void tallq_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, float* slabs,
+                  double* rr_part, double* rr2_part, int nwg, hipStream_t st) {
+  hipLaunchKernelGGL((fos::gemv_tall_quad_kernel<T, VEC, WITH_G, DUAL>), dim3(nwg), dim3(fos::TL_THREADS), 0, st,
+                     reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part, rr2_part);
+}
+// 33..64 columns: a row per quad of lanes (gemv_tall_quad_kernel)
+#define TALLQ(DT, T, VEC) \
+  { DT, fos::TL_THREADS, 0, 0, tallq_launch<T, VEC, true, false>, tallq_launch<T, VEC, false, false>, \
+    tallq_launch<T, VEC, true, true> }
 #define TALL(DT, T, NC, LD) \
   { DT, fos::TL_THREADS, 0, 0, tall_launch<T, NC, LD, true, false>, tall_launch<T, NC, LD, false, false>, \
     tall_launch<T, NC, LD, true, true> }
@@ -113,16 +123,16 @@ void tall_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, Y
 #define TALL_ROW(DT, T, NC) { TALL(DT, T, NC, fos::TL_DIRECT), TALL(DT, T, NC, fos::TL_VEC), TALL(DT, T, NC, fos::TL_STAGE) }
 const MenuEntry kTallF32[4][3] = {
     TALL_ROW(FOS_F32, float, 8), TALL_ROW(FOS_F32, float, 16), TALL_ROW(FOS_F32, float, 32),
-    {TALL_ND(FOS_F32, float, 64, fos::TL_DIRECT), TALL_ND(FOS_F32, float, 64, fos::TL_VEC),
-     TALL_ND(FOS_F32, float, 64, fos::TL_DIRECT)}};
+    {TALLQ(FOS_F32, float, false), TALLQ(FOS_F32, float, true), TALLQ(FOS_F32, float, false)}};
 const MenuEntry kTallBf16[4][2] = {
     {TALL(FOS_BF16, fos::bf16_t, 8, fos::TL_DIRECT), TALL(FOS_BF16, fos::bf16_t, 8, fos::TL_STAGE)},
     {TALL(FOS_BF16, fos::bf16_t, 16, fos::TL_DIRECT), TALL(FOS_BF16, fos::bf16_t, 16, fos::TL_STAGE)},
     {TALL(FOS_BF16, fos::bf16_t, 32, fos::TL_DIRECT), TALL(FOS_BF16, fos::bf16_t, 32, fos::TL_STAGE)},
-    {TALL_ND(FOS_BF16, fos::bf16_t, 64, fos::TL_DIRECT), TALL_ND(FOS_BF16, fos::bf16_t, 64, fos::TL_DIRECT)}};
+    {TALLQ(FOS_BF16, fos::bf16_t, false), TALLQ(FOS_BF16, fos::bf16_t, false)}};
 #undef TALL
 #undef TALL_ND
 #undef TALL_ROW
+#undef TALLQ
 // load form: 16-byte row loads when the layout allows, LDS staging for contiguous ragged matrices, scalar loads otherwise
 const MenuEntry* tall_entry(int dtype, int64_t n, int64_t lda, const void* A) {
   const int idx = n <= 8 ? 0 : n <= 16 ? 1 : n <= 32 ? 2 : 3;

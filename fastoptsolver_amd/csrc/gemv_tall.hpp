@@ -143,4 +143,113 @@ __global__ __launch_bounds__(TL_THREADS) void gemv_tall_kernel(const T* __restri
   });
 }
 
+// 33..64 columns: a row per QUAD of lanes, 16 columns per lane.  The row-per-thread form needs y, the row and 64 fp64
+// accumulators in one thread - 400 registers, one workgroup per CU, 37 % of the roofline at 2,000,000 x 64.  Here a
+// lane keeps 16 columns of everything; the four partial dots of a row meet through two quad_perm DPP moves, and the
+// per-lane gradient partials are folded through LDS once per workgroup.  Same output contract as gemv_tall_kernel.
+constexpr int TQ_CPL = 16;                 // columns per lane
+constexpr int TQ_ROWS = TL_THREADS / 4;    // rows per workgroup trip and per row slot (64)
+
+__device__ inline double quad_sum(double v) {
+  v += dpp_fetch<0xB1, 0xF>(v);            // quad_perm [1,0,3,2]
+  v += dpp_fetch<0x4E, 0xF>(v);            // quad_perm [2,3,0,1]
+  return v;
+}
+
+template <typename T, bool VEC, bool WITH_G, bool DUAL>
+__global__ __launch_bounds__(TL_THREADS) void gemv_tall_quad_kernel(const T* __restrict__ A, int64_t lda,
+                                                                   const float* __restrict__ b, int64_t m, int n, YSource ys,
+                                                                   int64_t rows_per_wg, float* __restrict__ slabs,
+                                                                   double* __restrict__ rr_part, double* __restrict__ rr2_part) {
+  constexpr int NW = TL_THREADS / 64, RPI = 2;
+  __shared__ double y_s[64];
+  __shared__ double x_s[DUAL ? 64 : 1];
+  __shared__ double gred[WITH_G ? TL_THREADS : 1][TQ_CPL];
+  __shared__ double red[NW][8];
+  if (ys.stopped != nullptr && *ys.stopped != 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = tid & 3, rslot = tid >> 2;                 // column block of this lane, row slot within a trip
+  const int cbase = sub * TQ_CPL;
+  const double beta = source_beta(ys);
+  const int sstride = tall_slab_stride(n);
+  if (tid < 64) {
+    y_s[tid] = tid < n ? source_y(ys, tid, beta) : 0.0;
+    if constexpr (DUAL) x_s[tid] = tid < n ? ys.x_cur[tid] : 0.0;
+  }
+  __syncthreads();
+  double yv[TQ_CPL], xv[DUAL ? TQ_CPL : 1];
+#pragma unroll
+  for (int c = 0; c < TQ_CPL; ++c) {
+    yv[c] = y_s[cbase + c];
+    if constexpr (DUAL) xv[c] = x_s[cbase + c];
+  }
+  double g[WITH_G ? TQ_CPL : 1];
+#pragma unroll
+  for (int c = 0; c < (WITH_G ? TQ_CPL : 1); ++c) g[c] = 0.0;
+  double rr = 0.0, rr2 = 0.0;
+  const int64_t row_lo = (int64_t)blockIdx.x * rows_per_wg;
+  int64_t row_hi = row_lo + rows_per_wg;
+  if (row_hi > m) row_hi = m;
+  for (int64_t row0 = row_lo; row0 < row_hi; row0 += RPI * TQ_ROWS) {
+    float a[RPI][TQ_CPL];
+    double bi[RPI];
+#pragma unroll
+    for (int u = 0; u < RPI; ++u) {
+      const int64_t row = row0 + u * TQ_ROWS + rslot;
+      const bool in = row < row_hi;
+      bi[u] = (in && b != nullptr) ? (double)b[row] : 0.0;
+      const T* ar = A + row * lda + cbase;
+      if constexpr (VEC) {
+#pragma unroll
+        for (int c = 0; c < TQ_CPL / 4; ++c) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (in && cbase + 4 * c < n) v = reinterpret_cast<const f32x4*>(ar)[c];       // cached: lines are shared
+          a[u][4 * c] = v.x; a[u][4 * c + 1] = v.y; a[u][4 * c + 2] = v.z; a[u][4 * c + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < TQ_CPL; ++c) a[u][c] = (in && cbase + c < n) ? elem_to_float<T>(ar[c]) : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RPI; ++u) {            // rows beyond row_hi: a = 0, b = 0 -> r = 0
+      double acc = 0.0, acc2 = 0.0;
+#pragma unroll
+      for (int c = 0; c < TQ_CPL; ++c) {
+        acc += (double)a[u][c] * yv[c];
+        if constexpr (DUAL) acc2 += (double)a[u][c] * xv[c];
+      }
+      acc = quad_sum(acc) - bi[u];             // all four lanes of the quad hold r_i
+      if (sub == 0) rr += acc * acc;
+      if constexpr (DUAL) {
+        acc2 = quad_sum(acc2) - bi[u];
+        if (sub == 0) rr2 += acc2 * acc2;
+      }
+      if constexpr (WITH_G) {
+#pragma unroll
+        for (int c = 0; c < TQ_CPL; ++c) g[c] += (double)a[u][c] * acc;
+      }
+    }
+  }
+  if constexpr (WITH_G) {
+#pragma unroll
+    for (int c = 0; c < TQ_CPL; ++c) gred[tid][c] = g[c];
+    __syncthreads();
+    if (tid < 64) {                            // column tid: held by the lanes with sub == tid / 16, one per row slot
+      const int sb = tid / TQ_CPL, c = tid % TQ_CPL;
+      double tot = 0.0;
+      for (int k = 0; k < TQ_ROWS; ++k) tot += gred[4 * k + sb][c];
+      if (tid < sstride) slabs[(int64_t)blockIdx.x * sstride + tid] = tid < n ? (float)tot : 0.f;
+    }
+  }
+  double tail[8] = {rr, rr2, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  wave_sum_n(tail);
+  if (lane == 0) { red[wave][0] = tail[0]; red[wave][1] = tail[1]; }
+  __syncthreads();
+  if (tid == 0) {
+    rr_part[blockIdx.x] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    if constexpr (DUAL) rr2_part[blockIdx.x] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+  }
+}
+
 }  // namespace fos
