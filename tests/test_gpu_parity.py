@@ -615,7 +615,7 @@ def test_history_chunking_is_transparent(fos, monkeypatch):
 
 
 def test_large_ragged_n_is_padded_onto_the_fused_path(fos):
-    """m*n >= 2^24 with n % 4 != 0: prepare() zero-pads the columns of its device copy so the single-pass kernel
+    """m*n >= 2^20 with n % 4 != 0 (n > 64): prepare() zero-pads the columns of its device copy so the single-pass kernel
     applies; padding must be invisible (lengths, values) in every entry point."""
     rng = np.random.default_rng(17)
     m, n = 4100, 4098
