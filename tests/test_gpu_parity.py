@@ -53,7 +53,8 @@ def test_gemv_pair(fos, m, n, with_b):
 
 
 def test_gemv_pair_paths_and_layouts(fos):
-    """Strided A (lda > n), misaligned views (two-pass fallback) and a misaligned y must agree with the fused path."""
+    """Strided A (lda > n), misaligned views (two-pass kernels when borrowed as they are, pad=False; a compact aligned
+    copy on the single pass by default from 2^20 elements on) and a misaligned y must agree with the fused path."""
     rng = np.random.default_rng(5)
     m, n = 1500, 1024
     big = torch.as_tensor(rng.standard_normal((m, n + 8)).astype(np.float32), device="cuda")
@@ -61,8 +62,9 @@ def test_gemv_pair_paths_and_layouts(fos):
     ybuf = torch.as_tensor(rng.standard_normal(n + 1).astype(np.float32), device="cuda")
     y = ybuf[1:]                                     # 4-byte aligned only
     ref = None
-    for name, view in (("aligned-strided", big[:, :n]), ("misaligned", big[:, 1:n + 1]), ("shifted4", big[:, 4:n + 4])):
-        prob = fos.prepare(view, b)
+    for name, view, pad in (("aligned-strided", big[:, :n], None), ("misaligned", big[:, 1:n + 1], False),
+                            ("misaligned-copied", big[:, 1:n + 1], None), ("shifted4", big[:, 4:n + 4], None)):
+        prob = fos.prepare(view, b, pad=pad)
         plan = prob.plan()
         assert plan["path"] == (1 if name == "misaligned" else 0), (name, plan)
         g = prob.gemv_pair(y, alpha2=0.0).cpu().numpy()
