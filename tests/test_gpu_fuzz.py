@@ -209,7 +209,13 @@ def test_random_shapes_and_layouts_gemv_pair(fos, seed):
     prob = fos.prepare(At, b)
     g = prob.gemv_pair(torch.as_tensor(y).cuda(), alpha2=0.25).cpu().numpy()
     g_ref, rr_ref = orc.gram_gradient(A, y.astype(np.float64), b.astype(np.float64), 0.25)
-    scale = max(np.linalg.norm(g_ref), 1e-6 * np.linalg.norm(A) * (np.linalg.norm(A @ y) + np.linalg.norm(b)))
-    assert np.linalg.norm(g - g_ref) / scale < 2e-6, (seed, m, n, pad, off, prob.plan())
+    # float32 resolution of the pass: r_i = A_i.y - b_i is formed with an absolute error of a few eps32 * (|A_i|.|y| +
+    # |b_i|) however small r_i itself is (m = 1, 2 rows with a nearly exact fit: seeds 438, 1409, 1444 of a 2000-case
+    # soak), grad = A^T r inherits it times |A|, ||r||^2 inherits 2|r| times it
+    eps32 = float(np.finfo(np.float32).eps)
+    dr = 4.0 * eps32 * float(np.linalg.norm(np.abs(A) @ np.abs(y.astype(np.float64)) + np.abs(b)))
+    r_norm = float(np.sqrt(rr_ref))
+    g_tol = 2e-6 * float(np.linalg.norm(g_ref)) + float(np.linalg.norm(A, 2)) * dr
+    assert np.linalg.norm(g - g_ref) <= g_tol, (seed, m, n, pad, off, prob.plan())
     rr = prob.residual_objective(torch.as_tensor(y).cuda())[0]
-    assert rr == pytest.approx(rr_ref, rel=5e-6, abs=1e-12), (seed, m, n, pad, off, prob.plan())
+    assert abs(rr - rr_ref) <= 5e-6 * rr_ref + 2.0 * r_norm * dr + dr * dr, (seed, m, n, pad, off, prob.plan())
