@@ -215,7 +215,7 @@ def test_random_shapes_and_layouts_gemv_pair(fos, seed):
     eps32 = float(np.finfo(np.float32).eps)
     dr = 4.0 * eps32 * float(np.linalg.norm(np.abs(A) @ np.abs(y.astype(np.float64)) + np.abs(b)))
     r_norm = float(np.sqrt(rr_ref))
-    g_tol = 2e-6 * float(np.linalg.norm(g_ref)) + float(np.linalg.norm(A, 2)) * dr
+    g_tol = 2e-6 * float(np.linalg.norm(g_ref)) + float(np.linalg.norm(A, 2) if m * n <= 1 << 16 else np.linalg.norm(A)) * dr
     assert np.linalg.norm(g - g_ref) <= g_tol, (seed, m, n, pad, off, prob.plan())
     rr = prob.residual_objective(torch.as_tensor(y).cuda())[0]
     assert abs(rr - rr_ref) <= 5e-6 * rr_ref + 2.0 * r_norm * dr + dr * dr, (seed, m, n, pad, off, prob.plan())
