@@ -14,6 +14,7 @@
 #include "gemv_multi.hpp"
 #include "gemv_pair.hpp"
 #include "gemv_tall.hpp"
+#include "gemv_wide.hpp"
 #include "lbfgs_kernels.hpp"
 #include "reduce_update.hpp"
 #include "resident.hpp"
@@ -96,6 +97,21 @@ const MenuEntry* default_entry(int dtype, int64_t n) {
     if (e.dtype == dtype && (int64_t)e.threads * e.k * epc_of(dtype) >= n) return &e;
   return nullptr;
 }
+
+// ---- wide rows (gemv_wide.hpp): 16384 < n <= 32768 fp32, y in LDS (dynamic shared memory above the 64 KiB default) ---
+template <bool WITH_G>
+void wide_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, float* slabs,
+                 double* rr_part, double* /*rr2_part*/, int nwg, hipStream_t st) {
+  static bool raised = false;
+  if (!raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fos::gemv_wide_kernel<WITH_G>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, fos::WD_MAX_N * (int)sizeof(float));
+    raised = true;
+  }
+  hipLaunchKernelGGL((fos::gemv_wide_kernel<WITH_G>), dim3(nwg), dim3(fos::WD_THREADS), (size_t)n * sizeof(float), st,
+                     reinterpret_cast<const float*>(A), lda, b, m, n, ys, rpw, slabs, rr_part);
+}
+const MenuEntry kWideF32 = {FOS_F32, fos::WD_THREADS, fos::WD_K, 1, wide_launch<true>, wide_launch<false>, nullptr};
 
 // ---- tall-skinny entries (gemv_tall.hpp): n <= 64, any m / lda; one entry per column capacity and load form --------
 template <typename T, int NC, int LOAD, bool WITH_G, bool DUAL>
@@ -489,6 +505,7 @@ int fos_problem_create(fos_problem** out, const void* A, int64_t m, int64_t n, i
   if (n <= fos::TL_MAX_N && getenv("FOS_NO_TALL") == nullptr)
     plan_tall(p, tall_entry(a_dtype, n, lda, A));
   else if (e) plan_fused(p, e, 0);
+  else if (vec_ok && a_dtype == FOS_F32 && n <= fos::WD_MAX_N && getenv("FOS_NO_WIDE") == nullptr) plan_fused(p, &kWideF32, 0);
   else plan_fallback(p);
   int rc = ensure_workspace(p);
   if (rc == FOS_OK) {

@@ -414,22 +414,30 @@ def test_bf16_elastic_net_fista_vs_oracle_on_rounded_A(fos):
     assert xt_.dtype == torch.float32 and _data.rel(xt_.cpu().numpy(), x_ref) < TOL
 
 
-def test_wide_n_uses_fallback_and_matches(fos):
-    """n beyond the fused kernel's register budget (fp32: 16384 columns) takes the two-pass path."""
-    rng = np.random.default_rng(4)
-    m, n = 96, 20000
+@pytest.mark.parametrize("m,n,path", [(96, 20000, 0), (700, 32768, 0), (257, 24580, 0), (3, 16388, 0), (64, 40000, 1)])
+def test_wide_rows(fos, m, n, path):
+    """Rows beyond the streaming kernel's register budget (fp32: 16384 columns): up to 32768 columns the single pass keeps
+    y in LDS (gemv_wide.hpp); wider still takes the two-pass kernels."""
+    rng = np.random.default_rng(m + n)
     A = rng.standard_normal((m, n)).astype(np.float32)
     b = rng.standard_normal(m).astype(np.float32)
     y = rng.standard_normal(n).astype(np.float32)
     prob = fos.prepare(A, b)
-    assert prob.plan()["path"] == 1
+    plan = prob.plan()
+    assert plan["path"] == path and (path == 1 or (plan["threads"], plan["chunks"]) == (512, 16)), plan
+    A64, b64 = A.astype(np.float64), b.astype(np.float64)
     g = prob.gemv_pair(_dev(y), alpha2=0.0).cpu().numpy()
-    g_ref, _ = orc.gram_gradient(A.astype(np.float64), y.astype(np.float64), b.astype(np.float64), 0.0)
+    g_ref, rr_ref = orc.gram_gradient(A64, y.astype(np.float64), b64, 0.0)
     assert _data.rel(g, g_ref) < TOL
-    x = fos.fista(prob, None, "lasso", 5.0, 0.0, max_iter=15, L=float(np.linalg.norm(A.astype(np.float64), 2) ** 2))
-    x_ref = orc.fista(A.astype(np.float64), b.astype(np.float64), "lasso", 5.0, 0.0, max_iter=15,
-                      L=float(np.linalg.norm(A.astype(np.float64), 2) ** 2))
-    assert _data.rel(x, x_ref) < TOL
+    assert prob.residual_objective(_dev(y))[0] == pytest.approx(rr_ref, rel=TOL)
+    L = float(np.linalg.norm(A64, 2) ** 2)
+    for kw in (dict(), dict(backtracking=True, t_init_factor=2.0), dict(return_history=True)):
+        out = fos.fista(prob, None, "lasso", 5.0, 0.0, max_iter=12, L=L, **kw)
+        ref = orc.fista(A64, b64, "lasso", 5.0, 0.0, max_iter=12, L=L, **kw)
+        x, x_ref = (out[0], ref[0]) if kw.get("return_history") else (out, ref)
+        assert _data.rel(x, x_ref) < TOL, kw
+        if kw.get("return_history"):
+            assert np.allclose(out[1]["obj"], ref[1]["obj"], rtol=TOL)
 
 
 def test_armijo_constant_is_read_at_call_time(fos, monkeypatch):
