@@ -42,6 +42,7 @@ SIGNATURES = {
     "fos_problem_profile_read": (_i32, [_vp, C.POINTER(_f64), C.POINTER(_i64)]),
     "fos_gemv_pair": (_i32, [_vp, _vp, _f32, _vp, _vp]),
     "fos_gemv_pair_f64": (_i32, [_vp, _vp, _f64, _vp, _vp]),
+    "fos_gemv_pair_dd": (_i32, [_vp, _vp, _f64, _vp]),
     "fos_residual_objective": (_i32, [_vp, _vp, _vp]),
     "fos_residual_batch": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "fos_power_iter": (_i32, [_vp, _vp, _i32, _f64, C.POINTER(_f64), C.POINTER(_i32)]),
@@ -71,6 +72,9 @@ SIGNATURES = {
     "fos_vec_axpby": (_i32, [_f64, _vp, _f64, _vp, _vp, _i64, _vp]),
     "fos_vec_stats_f64": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "fos_vec_axpby_f64": (_i32, [_f64, _vp, _f64, _vp, _vp, _i64, _vp]),
+    "fos_lbfgs_two_loop_dd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
+    "fos_vec_stats_dd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "fos_vec_axpby_dd": (_i32, [_f64, _vp, _f64, _vp, _vp, _i64, _vp]),
 }
 
 _lib = None

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -53,10 +54,56 @@ void fused_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, 
                      rr2_part);
 }
 
+// fp64-accumulating form (fos_gemv_pair_dd): y and the slabs are doubles
+typedef void (*FusedLaunchDD)(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw,
+                              double* slabs, double* rr_part, int nwg, hipStream_t st);
+// Dynamic shared memory above the 64 KiB default has to be granted per kernel AND per device (the attribute lives in
+// the device's code object); a bitmask of devices already served, updated atomically, keeps this thread-safe.
+template <typename K>
+int raise_dynamic_lds(K kernel, size_t bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return FOS_ERR_HIP;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return FOS_OK;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) !=
+      hipSuccess)
+    return FOS_ERR_HIP;
+  done.fetch_or(bit, std::memory_order_release);
+  return FOS_OK;
+}
+
+template <typename T, int THREADS, int K, int R, int MINW, bool YLDS>
+void fused_launch_dd(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, double* slabs,
+                     double* rr_part, int nwg, hipStream_t st) {
+  auto kern = fos::gemv_pair_kernel<T, THREADS, K, R, true, MINW, true, 2, false, false, false, double, YLDS>;
+  constexpr size_t lds = YLDS ? (size_t)THREADS * K * fos::ElemTraits<T>::EPC * sizeof(double) : 0;
+  if constexpr (lds > 65536) {
+    static std::atomic<uint64_t> done{0};
+    (void)raise_dynamic_lds(kern, lds, done);       // on failure the launch below fails and LAUNCH_CHECK reports it
+  }
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(THREADS), lds, st, reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs,
+                     rr_part, (double*)nullptr);
+}
+
 struct MenuEntry {
   int dtype, threads, k, r;
   FusedLaunch with_g, resid_only, dual;   // dual may be null (geometry without a DUAL instantiation)
+  FusedLaunchDD dd;                       // tall entries only: the same kernel writing fp64 slabs
 };
+// Streaming geometries of the fp64-accumulating pass, ordered by capacity.  y and the gradient slice cost two VGPRs
+// per column here, so the wide rows take 512 threads x 8 chunks (2 waves per SIMD, 256 VGPRs) instead of 1024 x 4.
+struct DdEntry { int dtype, threads, k, r; FusedLaunchDD fn; };
+#define DD_ENTRY(DT, T, TH, K, R, YL) { DT, TH, K, R, fused_launch_dd<T, TH, K, R, 2, YL> }
+const DdEntry kDdMenu[] = {
+    DD_ENTRY(FOS_F32, float, 64, 1, 4, false), DD_ENTRY(FOS_F32, float, 64, 2, 2, false),
+    DD_ENTRY(FOS_F32, float, 256, 1, 2, false), DD_ENTRY(FOS_F32, float, 256, 2, 2, false),
+    DD_ENTRY(FOS_F32, float, 256, 4, 1, false), DD_ENTRY(FOS_F32, float, 512, 4, 1, false),
+    DD_ENTRY(FOS_F32, float, 512, 8, 1, true),
+    DD_ENTRY(FOS_BF16, fos::bf16_t, 64, 1, 2, false), DD_ENTRY(FOS_BF16, fos::bf16_t, 256, 1, 2, false),
+    DD_ENTRY(FOS_BF16, fos::bf16_t, 256, 2, 1, false), DD_ENTRY(FOS_BF16, fos::bf16_t, 256, 4, 1, true),
+    DD_ENTRY(FOS_BF16, fos::bf16_t, 512, 4, 1, true),
+};
+#undef DD_ENTRY
 #define ENTRY(DT, T, TH, K, R, W) \
   { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, 2, false>, fused_launch<T, TH, K, R, W, false, 2, false>, nullptr }
 // NB register tiles in flight (profiles/r01_kbench_exp_*.log: 3 tiles are worth 1.5 % at n = 8192); D: with DUAL
@@ -102,12 +149,8 @@ const MenuEntry* default_entry(int dtype, int64_t n) {
 template <bool WITH_G>
 void wide_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, float* slabs,
                  double* rr_part, double* /*rr2_part*/, int nwg, hipStream_t st) {
-  static bool raised = false;
-  if (!raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fos::gemv_wide_kernel<WITH_G>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, fos::WD_MAX_N * (int)sizeof(float));
-    raised = true;
-  }
+  static std::atomic<uint64_t> done{0};
+  (void)raise_dynamic_lds(&fos::gemv_wide_kernel<WITH_G>, fos::WD_MAX_N * sizeof(float), done);   // failure: see LAUNCH_CHECK
   hipLaunchKernelGGL((fos::gemv_wide_kernel<WITH_G>), dim3(nwg), dim3(fos::WD_THREADS), (size_t)n * sizeof(float), st,
                      reinterpret_cast<const float*>(A), lda, b, m, n, ys, rpw, slabs, rr_part);
 }
@@ -120,6 +163,18 @@ void tall_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, Y
   hipLaunchKernelGGL((fos::gemv_tall_kernel<T, NC, LOAD, WITH_G, DUAL>), dim3(nwg), dim3(fos::TL_THREADS), 0, st,
                      reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part, rr2_part);
 }
+template <typename T, int NC, int LOAD>
+void tall_launch_dd(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, double* slabs,
+                    double* rr_part, int nwg, hipStream_t st) {
+  hipLaunchKernelGGL((fos::gemv_tall_kernel<T, NC, LOAD, true, false, double>), dim3(nwg), dim3(fos::TL_THREADS), 0, st,
+                     reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part, (double*)nullptr);
+}
+template <typename T, bool VEC>
+void tallq_launch_dd(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, double* slabs,
+                     double* rr_part, int nwg, hipStream_t st) {
+  hipLaunchKernelGGL((fos::gemv_tall_quad_kernel<T, VEC, true, false, double>), dim3(nwg), dim3(fos::TL_THREADS), 0, st,
+                     reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part, (double*)nullptr);
+}
 template <typename T, bool VEC, bool WITH_G, bool DUAL>
 void tallq_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, float* slabs,
                   double* rr_part, double* rr2_part, int nwg, hipStream_t st) {
@@ -129,14 +184,10 @@ void tallq_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, 
 // 33..64 columns: a row per quad of lanes (gemv_tall_quad_kernel)
 #define TALLQ(DT, T, VEC) \
   { DT, fos::TL_THREADS, 0, 0, tallq_launch<T, VEC, true, false>, tallq_launch<T, VEC, false, false>, \
-    tallq_launch<T, VEC, true, true> }
+    tallq_launch<T, VEC, true, true>, tallq_launch_dd<T, VEC> }
 #define TALL(DT, T, NC, LD) \
   { DT, fos::TL_THREADS, 0, 0, tall_launch<T, NC, LD, true, false>, tall_launch<T, NC, LD, false, false>, \
-    tall_launch<T, NC, LD, true, true> }
-// 64 columns: y, the row and the fp64 accumulators already fill the register file; no DUAL form (callers then take
-// the history objective from a residual pass of its own)
-#define TALL_ND(DT, T, NC, LD) \
-  { DT, fos::TL_THREADS, 0, 0, tall_launch<T, NC, LD, true, false>, tall_launch<T, NC, LD, false, false>, nullptr }
+    tall_launch<T, NC, LD, true, true>, tall_launch_dd<T, NC, LD> }
 #define TALL_ROW(DT, T, NC) { TALL(DT, T, NC, fos::TL_DIRECT), TALL(DT, T, NC, fos::TL_VEC), TALL(DT, T, NC, fos::TL_STAGE) }
 const MenuEntry kTallF32[4][3] = {
     TALL_ROW(FOS_F32, float, 8), TALL_ROW(FOS_F32, float, 16), TALL_ROW(FOS_F32, float, 32),
@@ -147,7 +198,6 @@ const MenuEntry kTallBf16[4][2] = {
     {TALL(FOS_BF16, fos::bf16_t, 32, fos::TL_DIRECT), TALL(FOS_BF16, fos::bf16_t, 32, fos::TL_STAGE)},
     {TALLQ(FOS_BF16, fos::bf16_t, false), TALLQ(FOS_BF16, fos::bf16_t, false)}};
 #undef TALL
-#undef TALL_ND
 #undef TALL_ROW
 #undef TALLQ
 // load form: 16-byte row loads when the layout allows, LDS staging for contiguous ragged matrices, scalar loads otherwise
@@ -194,6 +244,13 @@ struct fos_problem {
   double* rvec = nullptr;            // fallback: residual (m doubles)
   float* gbuf = nullptr;             // n + 4 floats (internal, or caller-owned after fos_problem_set_gbuf)
   float* gbuf_own = nullptr;
+  // fp64-accumulating pass (fos_gemv_pair_dd): own geometry and fp64 slabs, allocated on first use
+  const DdEntry* dd_entry = nullptr;
+  int dd_nwg = 0;
+  int64_t dd_rows_per_wg = 0;
+  double* slabs_dd = nullptr;
+  double* rr_dd = nullptr;
+  int dd_two_pass_chunks = 0;        // > 0: this shape runs the fp64 two-pass kernels for the dd pass
   float* ybuf = nullptr;             // n floats: aligned copy of a caller vector when needed
   double* dscal = nullptr;           // 128 device doubles (scalars, power-iteration history)
   double* part = nullptr;            // partial sums of the small kernels
@@ -475,6 +532,44 @@ int aligned_vec(fos_problem* p, const float* v, const float** out) {
   return FOS_OK;
 }
 
+// ---- fp64-accumulating pass (L-BFGS fg) -----------------------------------------------------------------------------
+// Geometry and workspace of fos_gemv_pair_dd, decided on first use: the tall kernels and the resident kernel serve it as
+// they are (they accumulate in fp64 anyway), streaming shapes get the ACC = double instantiation of gemv_pair_kernel,
+// everything else (ragged / misaligned layouts, rows wider than the dd menu) the fp64 two-pass kernels.
+int ensure_dd(fos_problem* p) {
+  if (p->slabs_dd || p->resident) return FOS_OK;
+  int nslabs = 0;
+  int64_t stride = p->n;
+  int n_rr = 0;
+  if (p->tall) {
+    nslabs = p->nwg; stride = p->slab_stride; n_rr = p->nwg;
+  } else {
+    const DdEntry* e = nullptr;
+    if (p->path == 0)
+      for (const auto& c : kDdMenu)
+        if (c.dtype == p->dtype && (int64_t)c.threads * c.k * epc_of(p->dtype) >= p->n) { e = &c; break; }
+    if (e) {
+      p->dd_entry = e;
+      int nwg = p->ncu * (e->threads >= 256 ? 1 : 512 / e->threads);
+      const int64_t min_rows = 2 * (int64_t)e->r;
+      if (p->m < (int64_t)nwg * min_rows) nwg = (int)std::max<int64_t>(1, p->m / min_rows);
+      p->dd_rows_per_wg = (p->m + nwg - 1) / nwg;
+      p->dd_nwg = (int)((p->m + p->dd_rows_per_wg - 1) / p->dd_rows_per_wg);
+      nslabs = p->dd_nwg; n_rr = p->dd_nwg;
+    } else {
+      const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(64, p->m / 64));
+      p->dd_rows_per_wg = (p->m + chunks - 1) / chunks;
+      p->dd_two_pass_chunks = (int)((p->m + p->dd_rows_per_wg - 1) / p->dd_rows_per_wg);
+      p->dd_nwg = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (p->m + 3) / 4));      // pass-1 grid
+      nslabs = p->dd_two_pass_chunks; n_rr = p->dd_nwg;
+      if (p->rvec == nullptr) HIP_TRY(hipMalloc(&p->rvec, (size_t)p->m * sizeof(double)));
+    }
+  }
+  HIP_TRY(hipMalloc(&p->rr_dd, (size_t)std::max(n_rr, 1) * sizeof(double)));
+  HIP_TRY(hipMalloc(&p->slabs_dd, (size_t)nslabs * stride * sizeof(double)));
+  return FOS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -547,7 +642,8 @@ int fos_problem_profile_read(fos_problem* p, double* ms_total, int64_t* launches
 int fos_problem_destroy(fos_problem* p) {
   if (!p) return FOS_OK;
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
-  void* bufs[] = {p->slabs, p->rr_part, p->rr2_part, p->rvec, p->gbuf_own, p->ybuf, p->dscal, p->part, p->xp, p->q_part, p->bt_out};
+  void* bufs[] = {p->slabs, p->rr_part, p->rr2_part, p->rvec, p->gbuf_own, p->ybuf, p->dscal, p->part, p->xp, p->q_part, p->bt_out,
+                  p->slabs_dd, p->rr_dd};
   for (void* q : bufs)
     if (q) (void)hipFree(q);
   delete p;
@@ -618,6 +714,57 @@ int fos_gemv_pair_f64(fos_problem* p, const double* y, double alpha2, float* gra
   if ((rc = launch_slab_reduce(p, n_rr, p->gbuf, rr_out, nullptr))) return rc;
   hipLaunchKernelGGL(fos::add_l2_kernel<double>, dim3(grid_1d(p->n, 256, 1024)), dim3(256), 0, p->stream, p->gbuf, alpha2,
                      y, grad, p->n);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
+int fos_gemv_pair_dd(fos_problem* p, const double* x, double alpha2, double* grad_rr) {
+  if (!p || !x || !grad_rr) return fail(FOS_ERR_ARG, "fos_gemv_pair_dd: null");
+  if (p->resident) {                           // small problem: one launch, fp64 throughout (resident.hpp)
+    if (p->dtype == FOS_F32)
+      hipLaunchKernelGGL((fos::gemv_pair_resident_kernel<float, double>), dim3(1), dim3(fos::RS_THREADS), 0, p->stream,
+                         (const float*)p->A, p->lda, p->b, (int)p->m, (int)p->n, x, alpha2, grad_rr, grad_rr + p->n);
+    else
+      hipLaunchKernelGGL((fos::gemv_pair_resident_kernel<fos::bf16_t, double>), dim3(1), dim3(fos::RS_THREADS), 0,
+                         p->stream, (const fos::bf16_t*)p->A, p->lda, p->b, (int)p->m, (int)p->n, x, alpha2, grad_rr,
+                         grad_rr + p->n);
+    LAUNCH_CHECK();
+    return FOS_OK;
+  }
+  int rc = ensure_dd(p);
+  if (rc) return rc;
+  YSource ys{nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, x};
+  int nslabs = 0, n_rr = 0;
+  int64_t stride = p->n;
+  if ((rc = prof_mark(p, true))) return rc;
+  if (p->tall) {
+    p->entry->dd(p->A, p->lda, p->b, p->m, (int)p->n, ys, p->rows_per_wg, p->slabs_dd, p->rr_dd, p->nwg, p->stream);
+    nslabs = n_rr = p->nwg;
+    stride = p->slab_stride;
+  } else if (p->dd_entry) {
+    p->dd_entry->fn(p->A, p->lda, p->b, p->m, (int)p->n, ys, p->dd_rows_per_wg, p->slabs_dd, p->rr_dd, p->dd_nwg, p->stream);
+    nslabs = n_rr = p->dd_nwg;
+  } else {
+    dim3 grid((unsigned)((p->n + 255) / 256), (unsigned)p->dd_two_pass_chunks);
+    if (p->dtype == FOS_F32) {
+      hipLaunchKernelGGL(fos::residual_rows_kernel<float>, dim3(p->dd_nwg), dim3(256), 0, p->stream, (const float*)p->A,
+                         p->lda, p->b, p->m, (int)p->n, ys, p->rvec, p->rr_dd);
+      hipLaunchKernelGGL((fos::transpose_rows_kernel<float, double>), grid, dim3(256), 0, p->stream, (const float*)p->A,
+                         p->lda, p->m, (int)p->n, p->rvec, (const int*)nullptr, p->dd_rows_per_wg, p->slabs_dd);
+    } else {
+      hipLaunchKernelGGL(fos::residual_rows_kernel<fos::bf16_t>, dim3(p->dd_nwg), dim3(256), 0, p->stream,
+                         (const fos::bf16_t*)p->A, p->lda, p->b, p->m, (int)p->n, ys, p->rvec, p->rr_dd);
+      hipLaunchKernelGGL((fos::transpose_rows_kernel<fos::bf16_t, double>), grid, dim3(256), 0, p->stream,
+                         (const fos::bf16_t*)p->A, p->lda, p->m, (int)p->n, p->rvec, (const int*)nullptr, p->dd_rows_per_wg,
+                         p->slabs_dd);
+    }
+    nslabs = p->dd_two_pass_chunks;
+    n_rr = p->dd_nwg;
+  }
+  LAUNCH_CHECK();
+  if ((rc = prof_mark(p, false))) return rc;
+  hipLaunchKernelGGL(fos::slab_reduce_dd_kernel, dim3((unsigned)((p->n + 127) / 128)), dim3(256), 0, p->stream, p->slabs_dd,
+                     nslabs, (int)p->n, stride, p->rr_dd, n_rr, alpha2, x, grad_rr);
   LAUNCH_CHECK();
   return FOS_OK;
 }
@@ -1297,13 +1444,49 @@ int fos_lbfgs_two_loop(const float* g, const float* S, const float* Y, int hist,
                                       reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(d_out)) & 15u) == 0;
   hipStream_t st = (hipStream_t)stream;
   const int capk = std::max(cap, 1);
-#define FOS_TL(NQ) hipLaunchKernelGGL(fos::lbfgs_two_loop_kernel<NQ>, dim3(1), dim3(fos::LB_THREADS), 0, st, g, S, Y, \
+#define FOS_TL(NQ) hipLaunchKernelGGL((fos::lbfgs_two_loop_kernel<float, NQ>), dim3(1), dim3(fos::LB_THREADS), 0, st, g, S, Y, \
                                       hist, head, capk, n, d_out)
   if (vec && n <= 4096) FOS_TL(1);
   else if (vec && n <= 8192) FOS_TL(2);
   else if (vec && n <= 16384) FOS_TL(4);
   else FOS_TL(0);
 #undef FOS_TL
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
+int fos_lbfgs_two_loop_dd(const double* g, const double* S, const double* Y, int hist, int head, int cap, int64_t n,
+                          double* d_out, void* stream) {
+  if (!g || !d_out || n <= 0 || hist < 0 || hist > fos::LB_MAXHIST || cap < hist || (hist > 0 && (!S || !Y)) ||
+      head < 0 || (cap > 0 && head >= cap))
+    return fail(FOS_ERR_ARG, "fos_lbfgs_two_loop_dd: bad argument");
+  const bool vec = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(S) |
+                                      reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(d_out)) & 31u) == 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int capk = std::max(cap, 1);
+#define FOS_TL(NQ) hipLaunchKernelGGL((fos::lbfgs_two_loop_kernel<double, NQ>), dim3(1), dim3(fos::LB_THREADS), 0, st, g, S, \
+                                      Y, hist, head, capk, n, d_out)
+  if (vec && n <= 4096) FOS_TL(1);
+  else if (vec && n <= 8192) FOS_TL(2);
+  else if (vec && n <= 16384) FOS_TL(4);
+  else FOS_TL(0);
+#undef FOS_TL
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
+int fos_vec_stats_dd(const double* x, const double* g, const double* d, int64_t n, double* out5, void* stream) {
+  if (!out5 || n <= 0) return fail(FOS_ERR_ARG, "fos_vec_stats_dd: bad argument");
+  hipLaunchKernelGGL((fos::vec_stats_kernel<double, double>), dim3(1), dim3(fos::LB_THREADS), 0, (hipStream_t)stream, x, g,
+                     d, n, out5);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
+int fos_vec_axpby_dd(double a, const double* x, double b, const double* y, double* out, int64_t n, void* stream) {
+  if (!x || !out || n <= 0 || (b != 0.0 && !y)) return fail(FOS_ERR_ARG, "fos_vec_axpby_dd: bad argument");
+  hipLaunchKernelGGL(fos::vec_axpby_f64_kernel<double>, dim3(grid_1d(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, a,
+                     x, b, b != 0.0 ? y : nullptr, out, n);
   LAUNCH_CHECK();
   return FOS_OK;
 }
@@ -1326,7 +1509,7 @@ int fos_vec_stats_f64(const double* x, const float* g, const float* d, int64_t n
 
 int fos_vec_axpby_f64(double a, const double* x, double b, const float* y, double* out, int64_t n, void* stream) {
   if (!x || !out || n <= 0 || (b != 0.0 && !y)) return fail(FOS_ERR_ARG, "fos_vec_axpby_f64: bad argument");
-  hipLaunchKernelGGL(fos::vec_axpby_f64_kernel, dim3(grid_1d(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, a, x, b,
+  hipLaunchKernelGGL(fos::vec_axpby_f64_kernel<float>, dim3(grid_1d(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, a, x, b,
                      b != 0.0 ? y : nullptr, out, n);
   LAUNCH_CHECK();
   return FOS_OK;

@@ -24,6 +24,11 @@ namespace fos {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+// a (an element of A, exact in either type) times y plus acc in the accumulator's type
+__device__ inline float fma_acc(float a, float y, float acc) { return fmaf(a, y, acc); }
+__device__ inline double fma_acc(float a, double y, double acc) { return fma((double)a, y, acc); }
 
 __device__ inline double form_y(double xc, double xp, double beta) { return xc + beta * (xc - xp); }
 
@@ -145,16 +150,26 @@ __device__ inline double wave_sum(double v) { return wave_sum_dpp(v); }   // fp6
 // the gradient at y_k, instead of the extra pass the reference pays per iteration.
 // DRAIN = true waits for ALL outstanding loads (also the tile just prefetched) before each consume: a bursty
 // request pattern that measured 2-3 % faster than the continuously overlapped one for 64 KiB rows (n = 16384 fp32).
+// ACC = double: the L-BFGS `fg` form (lbfgs.py:43-54 through SciPy's float64 optimiser).  y is taken in fp64 and never
+// rounded, every product a_ij*y_j and a_ij*r_i is formed in fp64 (exact: 24 x 53 bits round once in the fma), row dots,
+// the wave / workgroup reductions and the gradient slice accumulate in fp64 and the slab is written as doubles.  The pass
+// stays HBM-bound: per 16-byte chunk it costs 4 v_cvt_f64_f32 + 8 v_fma_f64 against ~5 cycles of HBM time per CU
+// (DESIGN.md "L-BFGS in fp64"); registers, not VALU, are what it pays with (yv and gv double in size).
+// YLDS = true (ACC = double only) keeps y in LDS instead (THREADS*K*EPC doubles of dynamic shared memory, up to 128 KiB
+// of the CU's 160 KiB): the geometries for 64 KiB rows would otherwise need y + gradient slice = 256 KiB of the CU's
+// 512 KiB register file plus two row tiles, and spill.  LDS read traffic is 8 bytes per element of A, ~26 B/clk/CU.
 template <typename T, int THREADS, int K, int R, bool NT, int MINW, bool WITH_G = true, int NBUF = 2, bool IL = false,
-          bool DUAL = false, bool DRAIN = false>
+          bool DUAL = false, bool DRAIN = false, typename ACC = float, bool YLDS = false>
 __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
     const T* __restrict__ A, int64_t lda, const float* __restrict__ b, int64_t m, int n, YSource ys,
-    int64_t rows_per_wg, float* __restrict__ slabs, double* __restrict__ rr_part, double* __restrict__ rr2_part) {
+    int64_t rows_per_wg, ACC* __restrict__ slabs, double* __restrict__ rr_part, double* __restrict__ rr2_part) {
   using Tr = ElemTraits<T>;
   constexpr int EPC = Tr::EPC;
   constexpr int NW = THREADS / 64;
   constexpr int NV = DUAL ? 2 : 1;
-  __shared__ float red[2][R * NV][NW];
+  __shared__ ACC red[2][R * NV][NW];
+  extern __shared__ __attribute__((aligned(16))) double y_lds[];      // YLDS only: THREADS*K*EPC doubles
+  static_assert(!YLDS || (sizeof(ACC) == 8 && !DUAL), "YLDS is the fp64 form without DUAL");
 
   if (ys.stopped != nullptr && *ys.stopped != 0) return;
 
@@ -166,9 +181,9 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
   if (row_hi > m) row_hi = m;
 
   // ---- prologue: this thread's slice of y, straight into registers --------------------------------
-  float yv[K][EPC];
-  float gv[K][EPC];
-  float xv[DUAL ? K : 1][EPC];
+  ACC yv[YLDS ? 1 : K][EPC];
+  ACC gv[K][EPC];
+  ACC xv[DUAL ? K : 1][EPC];
   bool live[K];
   const double beta = source_beta(ys);
 #pragma unroll
@@ -176,12 +191,15 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
     const int col = (c * THREADS + tid) * EPC;
     live[c] = col < n;
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { yv[c][e] = 0.f; gv[c][e] = 0.f; }
+    for (int e = 0; e < EPC; ++e) { gv[c][e] = (ACC)0; if constexpr (!YLDS) yv[c][e] = (ACC)0; }
     if constexpr (DUAL) {
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) xv[c][e] = live[c] ? (float)ys.x_cur[col + e] : 0.f;
+      for (int e = 0; e < EPC; ++e) xv[c][e] = live[c] ? (ACC)ys.x_cur[col + e] : (ACC)0;
     }
-    if (live[c]) {
+    if constexpr (YLDS) {                                    // dead chunks read zeros
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) y_lds[col + e] = live[c] ? source_y(ys, col + e, beta) : 0.0;
+    } else if (live[c]) {
 #pragma unroll
       for (int q = 0; q < EPC / 4; ++q) {
         if (ys.y != nullptr) {
@@ -190,11 +208,13 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
         } else {
           // same form_y as the update kernel -> both kernels see the same y_k
 #pragma unroll
-          for (int e = 0; e < 4; ++e) yv[c][4 * q + e] = (float)source_y(ys, col + 4 * q + e, beta);
+          for (int e = 0; e < 4; ++e) yv[c][4 * q + e] = (ACC)source_y(ys, col + 4 * q + e, beta);
         }
       }
     }
   }
+
+  if constexpr (YLDS) __syncthreads();      // (every thread wrote only the y entries it reads itself; kept for clarity)
 
   // Branch-free loads: a chunk beyond n reads this thread's chunk 0 instead (always inside the row when the
   // workgroup has any live chunk at all; its y slice is zero and its gradient slice is never stored).  Predicating
@@ -231,21 +251,30 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
     }
   };
   auto consume = [&](int buf, int64_t step) {
-    float part[R * NV];
+    ACC part[R * NV];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+      ACC acc0 = (ACC)0, acc1 = (ACC)0, acc2 = (ACC)0, acc3 = (ACC)0;
 #pragma unroll
       for (int c = 0; c < K; ++c) {
         float a[EPC];
         Tr::unpack(tile[buf][r][c], a);
+        ACC yl[EPC];
+        if constexpr (YLDS) {
+#pragma unroll
+          for (int q = 0; q < EPC / 2; ++q) {
+            const f64x2 t = *reinterpret_cast<const f64x2*>(y_lds + (c * THREADS + tid) * EPC + 2 * q);
+            yl[2 * q] = (ACC)t.x; yl[2 * q + 1] = (ACC)t.y;
+          }
+        }
 #pragma unroll
         for (int e = 0; e < EPC; e += 2) {
-          acc0 = fmaf(a[e], yv[c][e], acc0);
-          acc1 = fmaf(a[e + 1], yv[c][e + 1], acc1);
+          const ACC y0 = YLDS ? yl[e] : yv[c][e], y1 = YLDS ? yl[e + 1] : yv[c][e + 1];
+          acc0 = fma_acc(a[e], y0, acc0);
+          acc1 = fma_acc(a[e + 1], y1, acc1);
           if constexpr (DUAL) {
-            acc2 = fmaf(a[e], xv[c][e], acc2);
-            acc3 = fmaf(a[e + 1], xv[c][e + 1], acc3);
+            acc2 = fma_acc(a[e], xv[c][e], acc2);
+            acc3 = fma_acc(a[e + 1], xv[c][e + 1], acc3);
           }
         }
       }
@@ -258,23 +287,23 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
       for (int r = 0; r < R * NV; ++r) red[pb][r][wave] = part[r];
     }
     __syncthreads();
-    float res[R];
+    ACC res[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      float s = 0.f;
+      ACC s = (ACC)0;
 #pragma unroll
       for (int w = 0; w < NW; ++w) s += red[pb][r][w];
       const int64_t row = row_lo + first + step * group + r;
-      const float bi = b != nullptr ? bval[buf][r] : 0.f;
+      const ACC bi = b != nullptr ? (ACC)bval[buf][r] : (ACC)0;
       if (row < row_hi) {
         s -= bi;
         rr += (double)s * (double)s;
       } else {
-        s = 0.f;
+        s = (ACC)0;
       }
       res[r] = s;
       if constexpr (DUAL) {
-        float s2 = 0.f;
+        ACC s2 = (ACC)0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) s2 += red[pb][R + r][w];
         if (row < row_hi) { s2 -= bi; rr2 += (double)s2 * (double)s2; }
@@ -286,9 +315,17 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
 #pragma unroll
         for (int c = 0; c < K; ++c) {
           float a[EPC];
-          Tr::unpack(tile[buf][r][c], a);
+          if constexpr (sizeof(ACC) == 8) {
+            // fp64 form: hide the tile from value numbering, or the compiler keeps the v_cvt_f64_f32 results of the dot
+            // phase alive across the barrier for reuse here (2 VGPRs per element of the tile: spills at 64 KiB rows)
+            u32x4 t = tile[buf][r][c];
+            asm volatile("" : "+v"(t));
+            Tr::unpack(t, a);
+          } else {
+            Tr::unpack(tile[buf][r][c], a);
+          }
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) gv[c][e] = fmaf(a[e], res[r], gv[c][e]);
+          for (int e = 0; e < EPC; ++e) gv[c][e] = fma_acc(a[e], res[r], gv[c][e]);
         }
       }
     }
@@ -322,15 +359,21 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
   }
 
   // ---- epilogue: this workgroup's slab -------------------------------------------------------------
-  float* slab = slabs + (int64_t)blockIdx.x * n;
+  ACC* slab = slabs + (int64_t)blockIdx.x * n;
 #pragma unroll
   for (int c = 0; c < K; ++c) {
     if (WITH_G && live[c]) {
       const int col = (c * THREADS + tid) * EPC;
 #pragma unroll
       for (int q = 0; q < EPC / 4; ++q) {
-        f32x4 o = {gv[c][4 * q + 0], gv[c][4 * q + 1], gv[c][4 * q + 2], gv[c][4 * q + 3]};
-        *reinterpret_cast<f32x4*>(slab + col + 4 * q) = o;
+        if constexpr (sizeof(ACC) == 4) {
+          f32x4 o = {(float)gv[c][4 * q + 0], (float)gv[c][4 * q + 1], (float)gv[c][4 * q + 2], (float)gv[c][4 * q + 3]};
+          *reinterpret_cast<f32x4*>(slab + col + 4 * q) = o;
+        } else {
+          f64x2 o0 = {(double)gv[c][4 * q + 0], (double)gv[c][4 * q + 1]}, o1 = {(double)gv[c][4 * q + 2], (double)gv[c][4 * q + 3]};
+          *reinterpret_cast<f64x2*>(slab + col + 4 * q) = o0;
+          *reinterpret_cast<f64x2*>(slab + col + 4 * q + 2) = o1;
+        }
       }
     }
   }
@@ -375,10 +418,10 @@ __global__ __launch_bounds__(256) void residual_rows_kernel(const T* __restrict_
 }
 
 // grid = (ceil(n/256), nchunks): block (cx, cy) sums rows of chunk cy for 256 columns -> slab[cy].
-template <typename T>
+template <typename T, typename ST = float>
 __global__ __launch_bounds__(256) void transpose_rows_kernel(const T* __restrict__ A, int64_t lda, int64_t m, int n,
                                                             const double* __restrict__ r, const int* stopped,
-                                                            int64_t rows_per_chunk, float* __restrict__ slabs) {
+                                                            int64_t rows_per_chunk, ST* __restrict__ slabs) {
   if (stopped != nullptr && *stopped != 0) return;
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int64_t lo = (int64_t)blockIdx.y * rows_per_chunk;
@@ -387,7 +430,7 @@ __global__ __launch_bounds__(256) void transpose_rows_kernel(const T* __restrict
   if (j >= n) return;
   double acc = 0.0;
   for (int64_t row = lo; row < hi; ++row) acc += (double)elem_to_float<T>(A[row * lda + j]) * r[row];
-  slabs[(int64_t)blockIdx.y * n + j] = (float)acc;
+  slabs[(int64_t)blockIdx.y * n + j] = (ST)acc;
 }
 
 }  // namespace fos

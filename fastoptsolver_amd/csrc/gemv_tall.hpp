@@ -7,7 +7,8 @@
 // (A is row-major), the dot with y and the rank-1 update of the gradient happen in that thread's registers, and one
 // block reduction per workgroup ends the pass.  y (and x_k for DUAL) sits in LDS as doubles (broadcast reads); the
 // row dots, ||r||^2 and the gradient accumulators are fp64 (these problems are the ill-conditioned ones, cond 1e9 for
-// the unstandardised Boston features), the slab written per workgroup is fp32 like every other path.
+// the unstandardised Boston features), the slab written per workgroup is fp32 like every other path (fp64 in the ST = double form that serves the L-BFGS
+// fg, fos_gemv_pair_dd).
 // Output contract = gemv_pair_kernel except for the slab row stride: slabs[wg][tall_slab_stride(n)] (zero padded),
 // rr_part[wg], rr2_part[wg] (DUAL), rows [wg*rows_per_wg, ...).
 #pragma once
@@ -27,10 +28,10 @@ __host__ __device__ inline int tall_slab_stride(int n) { return (n + 3) & ~3; }
 //              span of memory - into LDS with fully coalesced loads, and each thread then reads its row from LDS
 //              (stride n words: conflict-free for odd n); NC <= 32 (LDS budget)
 enum : int { TL_DIRECT = 0, TL_VEC = 1, TL_STAGE = 2 };
-template <typename T, int NC, int LOAD, bool WITH_G, bool DUAL>
+template <typename T, int NC, int LOAD, bool WITH_G, bool DUAL, typename ST = float>
 __global__ __launch_bounds__(TL_THREADS) void gemv_tall_kernel(const T* __restrict__ A, int64_t lda,
                                                               const float* __restrict__ b, int64_t m, int n, YSource ys,
-                                                              int64_t rows_per_wg, float* __restrict__ slabs,
+                                                              int64_t rows_per_wg, ST* __restrict__ slabs,
                                                               double* __restrict__ rr_part, double* __restrict__ rr2_part) {
   constexpr int NW = TL_THREADS / 64;
   constexpr bool VEC = (LOAD == TL_VEC), STAGE = (LOAD == TL_STAGE);
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(TL_THREADS) void gemv_tall_kernel(const T* __restri
 #pragma unroll
       for (int c = 0; c < 8; ++c) v[c] = g[c0 + c];
       block_reduce8(v, [&](int c, double tot) {      // slab rows are padded to a multiple of 4 floats (zeros): the
-        if (c0 + c < sstride) slabs[(int64_t)blockIdx.x * sstride + c0 + c] = (float)tot;   // float4 epilogues take any n
+        if (c0 + c < sstride) slabs[(int64_t)blockIdx.x * sstride + c0 + c] = (ST)tot;   // float4 epilogues take any n
       });
     }
   }
@@ -156,10 +157,10 @@ __device__ inline double quad_sum(double v) {
   return v;
 }
 
-template <typename T, bool VEC, bool WITH_G, bool DUAL>
+template <typename T, bool VEC, bool WITH_G, bool DUAL, typename ST = float>
 __global__ __launch_bounds__(TL_THREADS) void gemv_tall_quad_kernel(const T* __restrict__ A, int64_t lda,
                                                                    const float* __restrict__ b, int64_t m, int n, YSource ys,
-                                                                   int64_t rows_per_wg, float* __restrict__ slabs,
+                                                                   int64_t rows_per_wg, ST* __restrict__ slabs,
                                                                    double* __restrict__ rr_part, double* __restrict__ rr2_part) {
   constexpr int NW = TL_THREADS / 64, RPI = 2;
   __shared__ double y_s[64];
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(TL_THREADS) void gemv_tall_quad_kernel(const T* __r
       const int sb = tid / TQ_CPL, c = tid % TQ_CPL;
       double tot = 0.0;
       for (int k = 0; k < TQ_ROWS; ++k) tot += gred[4 * k + sb][c];
-      if (tid < sstride) slabs[(int64_t)blockIdx.x * sstride + tid] = tid < n ? (float)tot : 0.f;
+      if (tid < sstride) slabs[(int64_t)blockIdx.x * sstride + tid] = tid < n ? (ST)tot : (ST)0;
     }
   }
   double tail[8] = {rr, rr2, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};

@@ -40,50 +40,70 @@ __device__ inline void block_sum_bcast(double (&v)[NV], double (*lds)[LB_THREADS
   }
 }
 
-// NQ = float4 chunks of q per thread kept in REGISTERS (n <= NQ * 4096); NQ = 0: q lives in global memory
+// Four consecutive elements of a float / double vector (16-byte aligned for float, 32-byte for double).
+__device__ inline void load4(const float* p, double (&o)[4]) {
+  const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+  o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+}
+__device__ inline void load4(const double* p, double (&o)[4]) {
+  const f64x2 a = *reinterpret_cast<const f64x2*>(p), b = *reinterpret_cast<const f64x2*>(p + 2);
+  o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+}
+__device__ inline void store4(float* p, const double (&v)[4]) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ inline void store4(double* p, const double (&v)[4]) {
+  *reinterpret_cast<f64x2*>(p) = f64x2{v[0], v[1]};
+  *reinterpret_cast<f64x2*>(p + 2) = f64x2{v[2], v[3]};
+}
+
+// VT: element type of g, S, Y and d.  float: the storage type of the round-1 driver (q is rounded to fp32 after every
+// update, like a float32 NumPy vector would be).  double: SciPy's own precision (lbfgs.py:64) - q, the history and d are
+// fp64 end to end; this is what LBFGSSolver.fit uses.
+// NQ = 4-element chunks of q per thread kept in REGISTERS (n <= NQ * 4096); NQ = 0: q lives in global memory
 // (any n; each thread only ever touches its own elements, so no cross-thread hazard on q).
-template <int NQ>
-__global__ __launch_bounds__(LB_THREADS) void lbfgs_two_loop_kernel(const float* __restrict__ g,
-                                                                    const float* __restrict__ S,
-                                                                    const float* __restrict__ Y, int hist, int head,
-                                                                    int cap, int64_t n, float* __restrict__ qout) {
+template <typename VT, int NQ>
+__global__ __launch_bounds__(LB_THREADS) void lbfgs_two_loop_kernel(const VT* __restrict__ g,
+                                                                    const VT* __restrict__ S,
+                                                                    const VT* __restrict__ Y, int hist, int head,
+                                                                    int cap, int64_t n, VT* __restrict__ qout) {
   __shared__ double lds[3][LB_THREADS / 64];
   __shared__ double coef[LB_MAXHIST];
   __shared__ double rho[LB_MAXHIST];
   const int tid = threadIdx.x;
   constexpr int NR = NQ > 0 ? NQ : 1;
-  f32x4 q[NR];
-  const bool vec_ok = (NQ > 0);
+  double q[NR][4];                            // held in fp64; rounded to VT after every update (no-op for double)
   auto col_of = [&](int c) { return (int64_t)(c * LB_THREADS + tid) * 4; };
+  auto rnd = [](double v) { return (double)(VT)v; };
   if constexpr (NQ > 0) {
 #pragma unroll
     for (int c = 0; c < NQ; ++c) {
       const int64_t col = col_of(c);
-      q[c] = col < n ? *reinterpret_cast<const f32x4*>(g + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (col < n) load4(g + col, q[c]);
+      else q[c][0] = q[c][1] = q[c][2] = q[c][3] = 0.0;
     }
   } else {
     for (int64_t i = tid; i < n; i += LB_THREADS) qout[i] = g[i];
   }
-  (void)vec_ok;
   double sy_last = 1.0, yy_last = 1.0;
   for (int h = hist - 1; h >= 0; --h) {
     const int slot = (head + h) % cap;
-    const float* s = S + (int64_t)slot * n;
-    const float* y = Y + (int64_t)slot * n;
+    const VT* s = S + (int64_t)slot * n;
+    const VT* y = Y + (int64_t)slot * n;
     double acc[3] = {0.0, 0.0, 0.0};          // s.q, y.s, y.y
-    f32x4 yk[NR];
+    double yk[NR][4];
     if constexpr (NQ > 0) {
 #pragma unroll
       for (int c = 0; c < NQ; ++c) {
         const int64_t col = col_of(c);
-        f32x4 sv = {0.f, 0.f, 0.f, 0.f};
-        yk[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (col < n) { sv = *reinterpret_cast<const f32x4*>(s + col); yk[c] = *reinterpret_cast<const f32x4*>(y + col); }
+        double sv[4] = {0.0, 0.0, 0.0, 0.0};
+        yk[c][0] = yk[c][1] = yk[c][2] = yk[c][3] = 0.0;
+        if (col < n) { load4(s + col, sv); load4(y + col, yk[c]); }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          acc[0] += (double)sv[e] * (double)q[c][e];
-          acc[1] += (double)yk[c][e] * (double)sv[e];
-          acc[2] += (double)yk[c][e] * (double)yk[c][e];
+          acc[0] += sv[e] * q[c][e];
+          acc[1] += yk[c][e] * sv[e];
+          acc[2] += yk[c][e] * yk[c][e];
         }
       }
     } else {
@@ -103,9 +123,9 @@ __global__ __launch_bounds__(LB_THREADS) void lbfgs_two_loop_kernel(const float*
 #pragma unroll
       for (int c = 0; c < NQ; ++c)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) q[c][e] = (float)((double)q[c][e] - a * (double)yk[c][e]);
+        for (int e = 0; e < 4; ++e) q[c][e] = rnd(q[c][e] - a * yk[c][e]);
     } else {
-      for (int64_t i = tid; i < n; i += LB_THREADS) qout[i] = (float)((double)qout[i] - a * (double)y[i]);
+      for (int64_t i = tid; i < n; i += LB_THREADS) qout[i] = (VT)((double)qout[i] - a * (double)y[i]);
     }
   }
   __syncthreads();                            // coef / rho visible to everyone
@@ -115,26 +135,26 @@ __global__ __launch_bounds__(LB_THREADS) void lbfgs_two_loop_kernel(const float*
 #pragma unroll
       for (int c = 0; c < NQ; ++c)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) q[c][e] = (float)((double)q[c][e] * gam);
+        for (int e = 0; e < 4; ++e) q[c][e] = rnd(q[c][e] * gam);
     } else {
-      for (int64_t i = tid; i < n; i += LB_THREADS) qout[i] = (float)((double)qout[i] * gam);
+      for (int64_t i = tid; i < n; i += LB_THREADS) qout[i] = (VT)((double)qout[i] * gam);
     }
   }
   for (int h = 0; h < hist; ++h) {
     const int slot = (head + h) % cap;
-    const float* s = S + (int64_t)slot * n;
-    const float* y = Y + (int64_t)slot * n;
+    const VT* s = S + (int64_t)slot * n;
+    const VT* y = Y + (int64_t)slot * n;
     double acc[1] = {0.0};
-    f32x4 sk[NR];
+    double sk[NR][4];
     if constexpr (NQ > 0) {
 #pragma unroll
       for (int c = 0; c < NQ; ++c) {
         const int64_t col = col_of(c);
-        f32x4 yv = {0.f, 0.f, 0.f, 0.f};
-        sk[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (col < n) { yv = *reinterpret_cast<const f32x4*>(y + col); sk[c] = *reinterpret_cast<const f32x4*>(s + col); }
+        double yv[4] = {0.0, 0.0, 0.0, 0.0};
+        sk[c][0] = sk[c][1] = sk[c][2] = sk[c][3] = 0.0;
+        if (col < n) { load4(y + col, yv); load4(s + col, sk[c]); }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[0] += (double)yv[e] * (double)q[c][e];
+        for (int e = 0; e < 4; ++e) acc[0] += yv[e] * q[c][e];
       }
     } else {
       for (int64_t i = tid; i < n; i += LB_THREADS) acc[0] += (double)y[i] * (double)qout[i];
@@ -145,16 +165,17 @@ __global__ __launch_bounds__(LB_THREADS) void lbfgs_two_loop_kernel(const float*
 #pragma unroll
       for (int c = 0; c < NQ; ++c)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) q[c][e] = (float)((double)q[c][e] + w * (double)sk[c][e]);
+        for (int e = 0; e < 4; ++e) q[c][e] = rnd(q[c][e] + w * sk[c][e]);
     } else {
-      for (int64_t i = tid; i < n; i += LB_THREADS) qout[i] = (float)((double)qout[i] + w * (double)s[i]);
+      for (int64_t i = tid; i < n; i += LB_THREADS) qout[i] = (VT)((double)qout[i] + w * (double)s[i]);
     }
   }
   if constexpr (NQ > 0) {
 #pragma unroll
     for (int c = 0; c < NQ; ++c) {
       const int64_t col = col_of(c);
-      if (col < n) *reinterpret_cast<f32x4*>(qout + col) = -q[c];
+      const double neg[4] = {-q[c][0], -q[c][1], -q[c][2], -q[c][3]};
+      if (col < n) store4(qout + col, neg);
     }
   } else {
     for (int64_t i = tid; i < n; i += LB_THREADS) qout[i] = -qout[i];
@@ -163,9 +184,9 @@ __global__ __launch_bounds__(LB_THREADS) void lbfgs_two_loop_kernel(const float*
 
 // out5 = { x.x, g.d, d.d, max|g|, ||x||_1 }; any pointer may be NULL (its entries are then 0).  XT: float or double
 // iterate.
-template <typename XT>
-__global__ __launch_bounds__(LB_THREADS) void vec_stats_kernel(const XT* __restrict__ x, const float* __restrict__ g,
-                                                               const float* __restrict__ d, int64_t n,
+template <typename XT, typename GT = float>
+__global__ __launch_bounds__(LB_THREADS) void vec_stats_kernel(const XT* __restrict__ x, const GT* __restrict__ g,
+                                                               const GT* __restrict__ d, int64_t n,
                                                                double* __restrict__ out5) {
   __shared__ double lds[5][16];
   double xx = 0.0, gd = 0.0, dd = 0.0, gm = 0.0, x1 = 0.0;
@@ -229,13 +250,15 @@ __global__ __launch_bounds__(256) void add_l2_kernel(const float* __restrict__ g
     out[i] = alpha2 != 0.0 ? (float)((double)gbuf[i] + alpha2 * (double)y[i]) : gbuf[i];
 }
 
-// out (fp64) = a*x (fp64) + b*y (fp32): the L-BFGS trial point x_old + stp*d with the iterate kept in fp64.
+// out (fp64) = a*x (fp64) + b*y (YT = fp32 or fp64): the L-BFGS trial point x_old + stp*d with the iterate kept in fp64.
+// Each product and the sum round separately (no fma contraction): bit for bit what NumPy's `stp * d + x_old` gives.
+template <typename YT>
 __global__ __launch_bounds__(256) void vec_axpby_f64_kernel(double a, const double* __restrict__ x, double b,
-                                                            const float* __restrict__ y, double* __restrict__ out,
+                                                            const YT* __restrict__ y, double* __restrict__ out,
                                                             int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    double v = a * x[i];
-    if (y != nullptr) v += b * (double)y[i];
+    double v = __dmul_rn(a, x[i]);
+    if (y != nullptr) v = __dadd_rn(__dmul_rn(b, (double)y[i]), v);
     out[i] = v;
   }
 }

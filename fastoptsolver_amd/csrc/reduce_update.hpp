@@ -171,6 +171,48 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
+// fp64 slabs (fos_gemv_pair_dd, the L-BFGS fg): out[j] = sum_s slabs[s][j] + alpha2*y[j] in fp64, fixed order;
+// out[n] = sum of the rr partials.  One thread per column pair (16-byte loads), 256 columns per workgroup... the slabs
+// are nslabs x stride doubles (stride >= n).  grid = ceil(n / 128), 256 threads = 64 column pairs x 4 slab groups.
+__global__ __launch_bounds__(256) void slab_reduce_dd_kernel(const double* __restrict__ slabs, int nslabs, int n,
+                                                            int64_t stride, const double* __restrict__ rr_part, int n_rr,
+                                                            double alpha2, const double* __restrict__ y,
+                                                            double* __restrict__ out) {
+  __shared__ double lds[4][128];
+  const int pair = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int col = blockIdx.x * 128 + 2 * pair;
+  double a0 = 0.0, a1 = 0.0;
+  if (col + 1 < n && (stride & 1) == 0) {
+    for (int s = grp; s < nslabs; s += 4) {
+      const f64x2 v = *reinterpret_cast<const f64x2*>(slabs + (int64_t)s * stride + col);
+      a0 += v.x; a1 += v.y;
+    }
+  } else if (col < n) {
+    for (int s = grp; s < nslabs; s += 4) {
+      a0 += slabs[(int64_t)s * stride + col];
+      if (col + 1 < n) a1 += slabs[(int64_t)s * stride + col + 1];
+    }
+  }
+  lds[grp][2 * pair] = a0;
+  lds[grp][2 * pair + 1] = a1;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int c = blockIdx.x * 128 + threadIdx.x;
+    if (c < n) {
+      double tot = (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
+      if (alpha2 != 0.0) tot += alpha2 * y[c];
+      out[c] = tot;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x >= 192) {      // the last wave folds the rr partials (fixed order)
+    const int l = threadIdx.x - 192;
+    double s = 0.0;
+    for (int i = l; i < n_rr; i += 64) s += rr_part[i];
+    s = wave_sum(s);
+    if (l == 0) out[n] = s;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // FISTA update for RCOLS columns per workgroup.  FROM_SLABS: sum the slabs first (single-GPU fused path);
 // otherwise take the (all-reduced) gradient from gbuf.  Writes x_prev <- x_k, x_k <- x_next in place and

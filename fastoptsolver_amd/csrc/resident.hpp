@@ -339,14 +339,14 @@ __global__ __launch_bounds__(RS_THREADS) void fista_resident_kernel(const T* __r
 }
 
 // One gradient of a small problem in one launch, all in fp64 on the fp32-stored A (L-BFGS fg, lbfgs.py:43-54):
-// grad = A^T (A y - b) + alpha2 y (rounded to fp32 once, on output), *rr_out = ||A y - b||^2.  Three launches of the
+// grad = A^T (A y - b) + alpha2 y (GT = float: rounded to fp32 once, on output; GT = double: fos_gemv_pair_dd), *rr_out = ||A y - b||^2.  Three launches of the
 // streaming path (fp32 pass, slab reduce, +alpha2 y) become one, and the line search of L-BFGS - which compares
 // objective values that differ in the 7th digit near the solution - sees a float64-accurate f and grad.
-template <typename T>
+template <typename T, typename GT = float>
 __global__ __launch_bounds__(RS_THREADS) void gemv_pair_resident_kernel(const T* __restrict__ A, int64_t lda,
                                                                        const float* __restrict__ b, int m, int n,
                                                                        const double* __restrict__ y, double alpha2,
-                                                                       float* __restrict__ grad, double* __restrict__ rr_out) {
+                                                                       GT* __restrict__ grad, double* __restrict__ rr_out) {
   __shared__ double y_s[RS_MAX_N];
   __shared__ double red[RS_WAVES][RS_CHUNK + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(RS_THREADS) void gemv_pair_resident_kernel(const T*
 #pragma unroll
       for (int w = 0; w < RS_WAVES; ++w) tot += red[w][tid];
       if (tid == RS_CHUNK) { if (rr_out != nullptr) *rr_out = tot; }
-      else grad[c0 + tid] = (float)(tot + alpha2 * y_s[c0 + tid]);
+      else grad[c0 + tid] = (GT)(tot + alpha2 * y_s[c0 + tid]);
     }
     __syncthreads();
   }

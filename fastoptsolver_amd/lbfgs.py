@@ -5,11 +5,13 @@ m=10, factr=1e7, maxls=20).  Here the unbounded L-BFGS-B iteration is restated n
 single-pass GEMV-pair kernel (K2), the direction is the one-launch two-loop kernel (K4), the line search moves
 only scalars over the host (``_linesearch.py``) while its vector updates are device kernels.
 
-fp32 note (SURVEY.md §7 "L-BFGS in fp32"): the iterate x is float64 on the device (like the FISTA state), the
-gradient / direction / history vectors are float32, all dots and the loss accumulate in float64.  The
-``factr`` test (2.2e-9 relative) is below float32 resolution, so the search can hit its noise floor a few
-iterations before SciPy's float64 run stops; a line search that can make no further progress is treated as
-convergence, exactly as L-BFGS-B treats its own ABNORMAL_TERMINATION_IN_LNSRCH.
+Precision: SciPy's optimiser is float64 end to end (lbfgs.py:64), and its stopping test is a 2.2e-9 RELATIVE change
+of f - far below what a float32 pass over A resolves.  So everything the optimiser sees is float64 here too: the
+iterate, gradient, direction and curvature pairs are fp64 device vectors, and ``fg`` is the fp64-accumulating
+instantiation of the single-pass kernel (``fos_gemv_pair_dd``: every a_ij*x_j and a_ij*r_i formed and summed in fp64,
+A and b as stored - fp32 / bf16).  The pass stays HBM-bound (one read of A).  What remains of float32 is the storage
+rounding of A and b themselves (6e-8 relative per entry): the run is SciPy's algorithm on that slightly perturbed
+problem, and reproduces SciPy's iterates to ~1e-7, its ``nit`` / ``nfev`` and its exit.
 """
 import numpy as np
 import torch
@@ -18,16 +20,13 @@ import torch.distributed as dist
 from . import _core, _lib
 from ._linesearch import LineSearch
 from .iterative_solvers import _EventTimer, grad_call_times, reset_metrics
-from .operators import vec_axpby
 
 _M, _FACTR, _MAXLS = 10, 1e7, 20
 _EPS = float(np.finfo(np.float64).eps)
-_EPS32 = float(np.finfo(np.float32).eps)
-_FLAT_TRIALS = 3     # consecutive trial points whose objective is indistinguishable from f(x_k) in float32
 
 
 class _HipOps:
-    """The device primitives of one fit: K2 pass, two-loop K4, n-vector kernels.  No CPU fallback."""
+    """The device primitives of one fit: fp64 K2 pass, fp64 two-loop K4, fp64 n-vector kernels.  No CPU fallback."""
 
     def __init__(self, A, b):
         self.lib = _lib.load()
@@ -46,45 +45,45 @@ class _HipOps:
         return torch.zeros(self.n, dtype=torch.float64, device=self.dev)
 
     def new_g(self):
-        return torch.empty(self.n, dtype=torch.float32, device=self.dev)
+        # n + 1 doubles: fos_gemv_pair_dd leaves ||r||^2 behind the gradient (the pair a sharded run all-reduces)
+        return torch.empty(self.n + 1, dtype=torch.float64, device=self.dev)[: self.n]
 
     def new_history(self, cap):
-        return (torch.zeros(cap, self.n, dtype=torch.float32, device=self.dev),
-                torch.zeros(cap, self.n, dtype=torch.float32, device=self.dev))
+        return (torch.zeros(cap, self.n, dtype=torch.float64, device=self.dev),
+                torch.zeros(cap, self.n, dtype=torch.float64, device=self.dev))
 
     def grad(self, x, a2, g):
         with torch.cuda.device(self.dev):
-            _lib.check(self.lib.fos_gemv_pair_f64(self.prob.h, _core.ptr(x), a2, _core.ptr(g), _core.ptr(self.rr)),
-                       "fos_gemv_pair_f64")
+            _lib.check(self.lib.fos_gemv_pair_dd(self.prob.h, _core.ptr(x), float(a2), _core.ptr(g)), "fos_gemv_pair_dd")
+        self.rr = g._base[self.n:]
 
     def stats(self, x, g, d):
         """Host list [x.x, g.d, d.d, max|g|, ||x||_1, ||r||^2 of the last grad()]: one launch, one read."""
+        self._stats[5:6].copy_(self.rr)
         with torch.cuda.device(self.dev):
-            if x is None:
-                _lib.check(self.lib.fos_vec_stats(None, _core.ptr(g), _core.ptr(d), self.n, _core.ptr(self._stats),
-                                                  _core.stream_ptr()), "fos_vec_stats")
-            else:
-                _lib.check(self.lib.fos_vec_stats_f64(_core.ptr(x), _core.ptr(g), _core.ptr(d), self.n,
-                                                      _core.ptr(self._stats), _core.stream_ptr()), "fos_vec_stats_f64")
+            _lib.check(self.lib.fos_vec_stats_dd(_core.ptr(x), _core.ptr(g), _core.ptr(d), self.n, _core.ptr(self._stats),
+                                                 _core.stream_ptr()), "fos_vec_stats_dd")
         return self._stats[:6].cpu().tolist()
 
     def direction(self, g, S, Y, hist, head):
-        d = torch.empty(self.n, dtype=torch.float32, device=self.dev)
+        d = torch.empty(self.n, dtype=torch.float64, device=self.dev)
         with torch.cuda.device(self.dev):
-            _lib.check(self.lib.fos_lbfgs_two_loop(_core.ptr(g), _core.ptr(S), _core.ptr(Y), hist, head, _M, self.n,
-                                                   _core.ptr(d), _core.stream_ptr()), "fos_lbfgs_two_loop")
+            _lib.check(self.lib.fos_lbfgs_two_loop_dd(_core.ptr(g), _core.ptr(S), _core.ptr(Y), hist, head, _M, self.n,
+                                                      _core.ptr(d), _core.stream_ptr()), "fos_lbfgs_two_loop_dd")
         return d
 
-    def step_to(self, x_old, stp, d):
-        out = torch.empty(self.n, dtype=torch.float64, device=self.dev)
+    def _axpby(self, a, x, b, y, out):
         with torch.cuda.device(self.dev):
-            _lib.check(self.lib.fos_vec_axpby_f64(1.0, _core.ptr(x_old), float(stp), _core.ptr(d), _core.ptr(out),
-                                                  self.n, _core.stream_ptr()), "fos_vec_axpby_f64")
+            _lib.check(self.lib.fos_vec_axpby_dd(float(a), _core.ptr(x), float(b), _core.ptr(y if b != 0.0 else None),
+                                                 _core.ptr(out), self.n, _core.stream_ptr()), "fos_vec_axpby_dd")
         return out
 
+    def step_to(self, x_old, stp, d):
+        return self._axpby(1.0, x_old, stp, d, torch.empty(self.n, dtype=torch.float64, device=self.dev))
+
     def store_pair(self, S, Y, slot, stp, d, g, g_old):
-        vec_axpby(stp, d, 0.0, None, out=S[slot])
-        vec_axpby(1.0, g, -1.0, g_old, out=Y[slot])
+        self._axpby(stp, d, 0.0, None, S[slot])
+        self._axpby(1.0, g, -1.0, g_old, Y[slot])
 
     def to_caller(self, x):
         return _core.from_device_vec(self.prob.vec_out(x), self.prob.like)
@@ -132,7 +131,7 @@ class LBFGSSolver:
 
         def fg(x, d):
             """loss, grad (device), and the scalars g.d, d.d, max|g| in one host read.   lbfgs.py:43-54
-            x is the fp64 iterate; the pass over A sees it rounded once to fp32 (kept in fp64 on the two-pass path)."""
+            x is the fp64 iterate and stays fp64 through the pass over A (fos_gemv_pair_dd)."""
             ev = gtimer.start()
             g = ops.new_g()
             ops.grad(x, a2_pass, g)                               # g = A_p^T (A_p x - b_p) [+ a2 x], ops.rr = ||r_p||^2
@@ -180,7 +179,7 @@ class LBFGSSolver:
             x_old, g_old, f_old = x, g, f
             ls = LineSearch()
             stp = ls.begin(stp, f_old, gd0)
-            evals, failed, gd1, flat = 0, False, gd0, 0
+            evals, failed, gd1 = 0, False, gd0
             while True:
                 if evals >= _MAXLS:
                     failed = True
@@ -192,19 +191,6 @@ class LBFGSSolver:
                 stp = ls.step(stp, f, gd1)
                 if ls.status != "FG":
                     break
-                # A pass over A in float32 resolves f only to ~eps32*|f|: once several trial points in a row
-                # are indistinguishable from f(x_k) the search cannot make progress (SURVEY §7 "L-BFGS in fp32").
-                flat = flat + 1 if abs(f - f_old) <= 4.0 * _EPS32 * max(abs(f_old), 1.0) else 0
-                if flat >= _FLAT_TRIALS:
-                    break
-            if flat >= _FLAT_TRIALS and ls.status == "FG":
-                if f <= f_old:
-                    nit += 1
-                    callback(x, f)
-                else:
-                    x, g, f = x_old, g_old, f_old
-                task = "CONVERGENCE: LINE SEARCH REACHED THE FLOAT32 RESOLUTION OF F"
-                break
             if failed or ls.status.startswith("ERROR"):
                 x, g, f = x_old, g_old, f_old
                 if hist == 0:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FOS_ABI_VERSION 2
+#define FOS_ABI_VERSION 3
 
 enum { FOS_OK = 0, FOS_ERR_ARG = -1, FOS_ERR_HIP = -2, FOS_ERR_STATE = -3, FOS_ERR_UNSUPPORTED = -4 };
 enum { FOS_F32 = 0, FOS_BF16 = 1 };                    /* element type of A */
@@ -98,6 +98,13 @@ int fos_gemv_pair(fos_problem* p, const float* y, float alpha2, float* grad, dou
 /* The same with the iterate y given in fp64 (n doubles): the L-BFGS driver keeps x in fp64 like the FISTA state;
  * y is rounded once to fp32 for the pass over A on the fused path and kept in fp64 on the two-pass path. */
 int fos_gemv_pair_f64(fos_problem* p, const double* y, double alpha2, float* grad, double* rr_out);
+
+/* The L-BFGS `fg` (lbfgs.py:43-54) at the precision SciPy's optimiser runs it in (lbfgs.py:64): x is n doubles and is
+ * never rounded, every product and every sum of the pass is fp64 (A and b are what the handle stores: fp32 / bf16),
+ * grad_rr[0..n) = A^T (A x - b) + alpha2*x, grad_rr[n] = ||A x - b||^2.  Still ONE read of A (the fp64-accumulating
+ * instantiation of the single-pass kernel; y in LDS for 64 KiB rows); ragged / misaligned layouts and rows wider than
+ * 16384 columns run fp64 two-pass kernels.  A sharded run all-reduces the n+1 doubles. */
+int fos_gemv_pair_dd(fos_problem* p, const double* x, double alpha2, double* grad_rr);
 
 /* K5: out3 (device doubles) = { ||A x - b||^2, ||x||_2^2, ||x||_1 } — one pass over A.
  * Replaces g_smooth iterative_solvers.py:163-168 and compute_objective objective_functions.py:13-24. */
@@ -193,6 +200,16 @@ int fos_vec_axpby(double a, const float* x, double b, const float* y, float* out
 /* fp64-iterate forms: x and out in fp64, g / d / y in fp32. */
 int fos_vec_stats_f64(const double* x, const float* g, const float* d, int64_t n, double* out5, void* stream);
 int fos_vec_axpby_f64(double a, const double* x, double b, const float* y, double* out, int64_t n, void* stream);
+
+/* All-fp64 forms (g, d, S, Y, x doubles): what LBFGSSolver.fit runs, so that the direction, the curvature pairs and the
+ * line-search scalars carry SciPy's precision.  Vectors 32-byte aligned for the register-resident two-loop kernel
+ * (any alignment works, through the generic form). */
+int fos_lbfgs_two_loop_dd(const double* g, const double* S, const double* Y, int hist, int head, int cap, int64_t n,
+                          double* d_out, void* stream);
+int fos_vec_stats_dd(const double* x, const double* g, const double* d, int64_t n, double* out5, void* stream);
+/* out = a*x + b*y with the two products and the sum rounded separately (no fma contraction): bit for bit NumPy's
+ * `stp * d + x_old`, `g - g_old`, `stp * d` (oracle lbfgs_minimize). */
+int fos_vec_axpby_dd(double a, const double* x, double b, const double* y, double* out, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -37,7 +37,7 @@ def test_every_symbol_exported(lib):
 
 
 def test_version_and_error_paths_without_gpu(lib):
-    assert lib.fos_abi_version() == 2
+    assert lib.fos_abi_version() == 3
     h = ctypes.c_void_p()
     # argument validation happens before any HIP call
     rc = lib.fos_problem_create(ctypes.byref(h), None, 4, 4, 4, 0, None, None)

@@ -90,14 +90,15 @@ def test_random_lbfgs(fos, seed):
     a2 = float(rng.choice([0.5, 5.0]))
     s = fos.LBFGSSolver("ridge", 0.0, a2, max_iter=12).fit(A, b)
     s_ref = orc.LBFGSSolver("ridge", 0.0, a2, max_iter=12).fit(A.astype(np.float64), b.astype(np.float64))
-    k = min(s.nit_, s_ref.nit_)
-    for i in range(k):
-        assert _data.rel(s.iterates_[i], s_ref.iterates_[i]) < 5e-5, (seed, i)
+    # the oracle runs on the same fp32-representable A and b, so the two runs differ by summation order only
+    assert (s.nit_, s.nfev_, s.task_) == (s_ref.nit_, s_ref.nfev_, s_ref.task_), (seed, s.task_, s_ref.task_)
+    for i in range(s.nit_):
+        assert _data.rel(s.iterates_[i], s_ref.iterates_[i]) < 1e-5, (seed, i)
     # closed form: (A^T A + a2 I)^-1 A^T b  (SURVEY 4 cross-check) when the run converged
     if s.task_.startswith("CONVERGENCE"):
         A64 = A.astype(np.float64)
         x_star = np.linalg.solve(A64.T @ A64 + a2 * np.eye(n), A64.T @ b.astype(np.float64))
-        assert _data.rel(s.x_, x_star) < 1e-4
+        assert _data.rel(s.x_, x_star) < 1e-4      # distance of L-BFGS's own stopping point (factr 1e7) from the optimum
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FOS_FUZZ_BT_SEEDS", "40"))))

@@ -277,8 +277,9 @@ def test_ista_vs_reference_goldens(fos, tag):
 
 @pytest.mark.parametrize("tag", ["tiny", "ragged", "aligned"])
 def test_lbfgs_vs_reference_goldens(fos, tag):
-    """fp32 vectors / fp64 scalars vs SciPy's fp64 iterates captured through lbfgs.py:64: compare iterate by
-    iterate up to the shorter run (the fp32 line search reaches its noise floor a few iterations early)."""
+    """SciPy's float64 iterates captured through lbfgs.py:64 vs the fp64 device optimiser on the fp32-stored A (every
+    sum of fg in fp64: fos_gemv_pair_dd): every iterate, the end point and the loss at the north-star tolerance, and
+    the same number of iterations and fg evaluations as SciPy, ending on SciPy's own exit."""
     A, b, fx = _data.problem(tag)
     prob = fos.prepare(A, b)
     n = 0
@@ -289,19 +290,46 @@ def test_lbfgs_vs_reference_goldens(fos, tag):
         s = fos.LBFGSSolver(c["reg"], c["alpha1"], c["alpha2"]).fit(prob, None)
         assert (s.reg_type, s.alpha1, s.alpha2) == (c["norm_reg"], c["norm_a1"], c["norm_a2"]), key
         ref_it = fx[key + "/iterates"]
-        nit_ref = len(ref_it)
-        for k in range(min(s.nit_, nit_ref)):
-            assert _data.rel(s.iterates_[k], ref_it[k]) < 2e-5, (key, k)
-        # float32 objective noise keeps the 2.2e-9 relative-reduction test from firing; the run goes on until
-        # the line search can no longer make progress (its noise floor), a few iterations after SciPy stops.
-        assert nit_ref - 4 <= s.nit_ <= nit_ref + 8, (key, s.nit_, nit_ref, s.task_)
-        assert _data.rel(s.x_, fx[key + "/x"]) < 2e-5, (key, s.task_)
-        assert s.final_obj_ == pytest.approx(float(fx[key + "/final_obj"]), rel=1e-5), key
+        nit_ref, nfev_ref = (int(v) for v in fx[key + "/nit_nfev"])
+        assert (s.nit_, s.nfev_) == (nit_ref, nfev_ref), (key, s.nit_, s.nfev_, s.task_)
+        assert s.task_ == "CONVERGENCE: REL_REDUCTION_OF_F_<=_FACTR*EPSMCH", (key, s.task_)
+        for k in range(nit_ref):
+            assert _data.rel(s.iterates_[k], ref_it[k]) < TOL, (key, k)
+        assert _data.rel(s.x_, fx[key + "/x"]) < TOL, (key, s.task_)
+        assert s.final_obj_ == pytest.approx(float(fx[key + "/final_obj"]), rel=1e-6), key
+        assert np.allclose(s.history_, fx[key + "/history"], rtol=1e-6), key     # callback objective (lbfgs.py:56-61)
         assert len(s.history_) == s.nit_ and fos.get_metrics()["grad_num_calls"] == s.nfev_
         n += 1
     assert n == 4
     with pytest.raises(ValueError):
         fos.LBFGSSolver("l0", 1.0, 1.0)
+
+
+def test_gemv_pair_dd_every_path(fos):
+    """fos_gemv_pair_dd (the fp64 fg of L-BFGS) through every kernel that serves it - resident, row-per-thread, every
+    streaming fp64 geometry (registers / y in LDS), fp64 two-pass for ragged and over-wide rows, bf16 storage - against
+    the fp64 oracle on the stored (rounded) A: 1e-12, i.e. only the summation order differs."""
+    from fastoptsolver_amd import _core, _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(17)
+    shapes = [(200, 5, "f32"), (3000, 7, "f32"), (5000, 40, "f32"), (333, 64, "bf16"),              # resident / tall
+              (700, 128, "f32"), (900, 512, "f32"), (600, 1024, "f32"), (777, 2048, "f32"), (513, 4096, "f32"),
+              (1200, 8192, "f32"), (1031, 16384, "f32"), (300, 12000, "f32"),                         # streaming fp32
+              (400, 256, "bf16"), (500, 2048, "bf16"), (300, 4096, "bf16"), (700, 8192, "bf16"), (520, 16384, "bf16"),
+              (257, 1023, "f32"), (64, 20000, "f32"), (100, 32768, "f32"), (90, 16392, "bf16")]       # two-pass fp64
+    for m, n, kind in shapes:
+        A = rng.standard_normal((m, n)).astype(np.float32)
+        At = torch.as_tensor(A).to(torch.bfloat16 if kind == "bf16" else torch.float32)
+        b = rng.standard_normal(m).astype(np.float32)
+        x = rng.standard_normal(n) * (1.0 + 1e-9 * rng.standard_normal(n))     # not representable in fp32
+        prob = fos.prepare(At.cuda(), b, pad=False)
+        xd = _dev(x, torch.float64)
+        out = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
+        _lib.check(lib.fos_gemv_pair_dd(prob.h, _core.ptr(xd), 0.37, _core.ptr(out)))
+        g_ref, rr_ref = orc.gram_gradient(At.to(torch.float64).numpy(), x, b.astype(np.float64), 0.37)
+        got = out.cpu().numpy()
+        assert _data.rel(got[:n], g_ref) < 1e-12, (m, n, kind, prob.plan())
+        assert got[n] == pytest.approx(rr_ref, rel=1e-12), (m, n, kind)
 
 
 def test_two_loop_kernel_vs_oracle(fos):
@@ -320,6 +348,12 @@ def test_two_loop_kernel_vs_oracle(fos):
         _lib.check(lib.fos_lbfgs_two_loop(_core.ptr(gd), _core.ptr(Sd), _core.ptr(Yd), hist, head, cap, n, _core.ptr(d),
                                           _core.stream_ptr()))
         assert _data.rel(d.cpu().numpy(), d_ref) < TOL, (n, hist)
+        # all-fp64 form (what LBFGSSolver.fit runs): only the summation order separates it from the oracle
+        S64, Y64, g64 = _dev(S, torch.float64), _dev(Y, torch.float64), _dev(g, torch.float64)
+        d64 = torch.empty(n, dtype=torch.float64, device="cuda")
+        _lib.check(lib.fos_lbfgs_two_loop_dd(_core.ptr(g64), _core.ptr(S64), _core.ptr(Y64), hist, head, cap, n,
+                                             _core.ptr(d64), _core.stream_ptr()))
+        assert _data.rel(d64.cpu().numpy(), d_ref) < 1e-12, (n, hist)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -382,6 +416,152 @@ def test_full_size_properties(fos):
     obj = np.array(h["obj"])
     assert np.all(np.diff(obj) <= 1e-6 * obj[:-1]) or obj[-1] < obj[0]
     assert np.isfinite(obj).all() and obj[-1] < obj[0]
+
+
+def _np(x):
+    return x.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(x) else np.asarray(x, dtype=np.float64)
+
+
+def _bench_like_problem(m, n, dtype, seed=0):
+    """A ~ N(0,1), b = A x_true + 0.1 N(0,1) generated on the device in 8192-row blocks (bench.py's recipe)."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    xt = torch.zeros(n, device="cuda")
+    idx = torch.randperm(n, device="cuda", generator=g)[: max(1, n // 20)]
+    xt[idx] = torch.randn(idx.numel(), device="cuda", generator=g)
+    A = torch.empty(m, n, dtype=dtype, device="cuda")
+    b = torch.empty(m, device="cuda")
+    for r0 in range(0, m, 8192):
+        r1 = min(m, r0 + 8192)
+        blk = torch.randn(r1 - r0, n, device="cuda", generator=g).to(dtype)
+        A[r0:r1] = blk
+        b[r0:r1] = blk.float() @ xt + 0.1 * torch.randn(r1 - r0, device="cuda", generator=g)
+    return A, b
+
+
+@pytest.mark.timeout(900)
+def test_cfg3_full_size_lbfgs(fos):
+    """BASELINE config 3 at full size (65536 x 8192 fp32, ridge alpha2 = 1): the device run against (a) the oracle's
+    L-BFGS on the same fp32-representable data in fp64 on the host - same nit, nfev, exit, end point to 1e-5 - and
+    (b) size-independent properties: gradient at the end point from an independent fp64 torch matmul, the optimum
+    of the normal equations solved in fp64 on the device, monotone callback history."""
+    m, n, a2 = 65536, 8192, 1.0
+    A, b = _bench_like_problem(m, n, torch.float32)
+    prob = fos.prepare(A, b)
+    assert prob.plan()["path"] == 0
+    s = fos.LBFGSSolver("ridge", 0.0, a2).fit(prob, None)
+    x = torch.as_tensor(_np(s.x_), dtype=torch.float64, device="cuda")     # tensor in -> float32 tensor out (6e-8)
+    # (b1) gradient at x_ by a second code path, in fp64, block by block
+    grad = a2 * x
+    rr = 0.0
+    for r0 in range(0, m, 8192):
+        Ab = A[r0:r0 + 8192].double()
+        r = Ab @ x - b[r0:r0 + 8192].double()
+        grad += Ab.T @ r
+        rr += float(r @ r)
+    f_indep = 0.5 * rr + 0.5 * a2 * float(x @ x)
+    assert s.final_obj_ == pytest.approx(f_indep, rel=1e-9)               # fg's fp64 loss IS the loss (x_ is at a minimum:
+                                                                          # its fp32 rounding moves f in second order only)
+    # (b2) optimum of the normal equations in fp64 on the device
+    H = torch.zeros(n, n, dtype=torch.float64, device="cuda")
+    rhs = torch.zeros(n, dtype=torch.float64, device="cuda")
+    for r0 in range(0, m, 8192):
+        Ab = A[r0:r0 + 8192].double()
+        H += Ab.T @ Ab
+        rhs += Ab.T @ b[r0:r0 + 8192].double()
+    H.diagonal().add_(a2)
+    x_star = torch.linalg.solve(H, rhs)
+    r_star = 0.0
+    for r0 in range(0, m, 8192):
+        r = A[r0:r0 + 8192].double() @ x_star - b[r0:r0 + 8192].double()
+        r_star += float(r @ r)
+    f_star = 0.5 * r_star + 0.5 * a2 * float(x_star @ x_star)
+    assert s.final_obj_ >= f_star * (1 - 1e-12) and s.final_obj_ == pytest.approx(f_star, rel=1e-7)
+    assert float((x - x_star).norm() / x_star.norm()) < 1e-4              # L-BFGS's own stopping distance (factr 1e7)
+    # scale of SciPy's exits: either the projected gradient is below pgtol or the last decrease was below factr*eps
+    assert s.task_.startswith("CONVERGENCE"), s.task_
+    assert float(grad.abs().max()) < 1e-2 * float(rhs.abs().max()) * 1e-3
+    hist = np.asarray(s.history_)
+    assert len(hist) == s.nit_ and np.all(np.diff(hist) <= 0.0)           # callback objective never increases
+    # (a) the oracle on the host, same data (fp32-representable), fp64 arithmetic
+    del H
+    A64 = A.cpu().numpy().astype(np.float64)
+    ref = orc.LBFGSSolver("ridge", 0.0, a2).fit(A64, b.cpu().numpy().astype(np.float64))
+    assert (s.nit_, s.nfev_, s.task_) == (ref.nit_, ref.nfev_, ref.task_), (s.nit_, s.nfev_, s.task_, ref.nit_, ref.nfev_)
+    assert _data.rel(_np(s.x_), ref.x_) < TOL
+    assert s.final_obj_ == pytest.approx(ref.final_obj_, rel=1e-9)
+    for k in range(s.nit_):
+        assert _data.rel(_np(s.iterates_[k]), ref.iterates_[k]) < TOL, k
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("kind", ["f32", "bf16"])
+def test_shard_size_properties(fos, kind):
+    """The per-GPU shard of BASELINE configs 4 / 5 (131072 x 16384, fp32 / bf16): the geometries the headline runs on
+    (1024-thread drained pipeline; 512 x 4 bf16), checked at that size through size-independent properties."""
+    m, n = 131072, 16384
+    dt = torch.float32 if kind == "f32" else torch.bfloat16
+    A, b = _bench_like_problem(m, n, dt, seed=1)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    y1 = torch.randn(n, device="cuda", generator=g)
+    y2 = torch.randn(n, device="cuda", generator=g)
+    prob = fos.prepare(A, b)
+    plan = prob.plan()
+    assert plan["path"] == 0 and (plan["threads"], plan["chunks"]) == ((1024, 4) if kind == "f32" else (512, 4)), plan
+    G = lambda y: prob.gemv_pair(y).double()                              # noqa: E731
+    # (1) affine
+    z = torch.zeros(n, device="cuda")
+    full = G(y1)
+    lin = G(y1 + y2) - full - G(y2) + G(z)
+    assert float(lin.norm() / G(y1 + y2).norm()) < 5e-6
+    # (2) against an independent fp64 matmul of the stored A, block by block (every row, not a subsample)
+    ref = torch.zeros(n, dtype=torch.float64, device="cuda")
+    rr_ref = 0.0
+    for r0 in range(0, m, 8192):
+        Ab = A[r0:r0 + 8192].double()
+        r = Ab @ y1.double() - b[r0:r0 + 8192].double()
+        ref += Ab.T @ r
+        rr_ref += float(r @ r)
+    assert float((full - ref).norm() / ref.norm()) < TOL
+    rr = torch.zeros(1, dtype=torch.float64, device="cuda")
+    prob.gemv_pair(y1, rr_out=rr)
+    assert float(rr) == pytest.approx(rr_ref, rel=TOL)
+    # (3) row subsample against the oracle itself
+    rows = slice(70000, 70512)
+    sub = fos.prepare(A[rows], b[rows])
+    g_ref, _ = orc.gram_gradient(A[rows].double().cpu().numpy(), y1.cpu().numpy().astype(np.float64),
+                                 b[rows].cpu().numpy().astype(np.float64), 0.0)
+    assert _data.rel(sub.gemv_pair(y1).cpu().numpy(), g_ref) < TOL
+    # (4) shard sum == whole (the decomposition the 8 ranks of configs 4 / 5 compute), fixed order
+    acc = torch.zeros(n, dtype=torch.float64, device="cuda")
+    for p in range(4):
+        sl = slice(p * m // 4, (p + 1) * m // 4)
+        acc += fos.prepare(A[sl], b[sl]).gemv_pair(y1).double()
+    assert float((acc - full).norm() / full.norm()) < 2e-6
+    # (5) bit reproducibility
+    assert torch.equal(prob.gemv_pair(y1), prob.gemv_pair(y1))
+    # (6) 10 solver iterations of the configuration's own regulariser against fp64 torch on the device
+    lam = float(ref.abs().max())
+    a1, a2 = (0.1 * lam, 0.0) if kind == "f32" else (0.05 * lam, 10.0)
+    np.random.seed(0)
+    L = fos.estimate_lipschitz(prob, n_iter=20)
+    x = fos.fista(prob, None, "lasso" if a2 == 0 else "elasticnet", a1, a2, max_iter=10, L=L)
+    tau = 1.0 / (L + (a2 if a2 > 0 else 0.0))
+    xk, tk = torch.zeros(n, dtype=torch.float64, device="cuda"), 1.0       # iterative_solvers.py:170-242 in fp64 torch
+    yk = xk.clone()
+    for _ in range(10):
+        gr = torch.zeros(n, dtype=torch.float64, device="cuda")
+        for r0 in range(0, m, 8192):
+            Ab = A[r0:r0 + 8192].double()
+            gr += Ab.T @ (Ab @ yk - b[r0:r0 + 8192].double())
+        if a2 > 0:
+            gr += a2 * yk
+        v = yk - tau * gr
+        xn = torch.sign(v) * torch.clamp(v.abs() - tau * a1, min=0.0)
+        tn = 0.5 * (1.0 + np.sqrt(1.0 + 4.0 * tk * tk))
+        yk = xn + ((tk - 1.0) / tn) * (xn - xk)
+        xk, tk = xn, tn
+    xg = torch.as_tensor(_np(x), dtype=torch.float64, device="cuda")
+    assert float((xg - xk).norm() / xk.norm()) < TOL
 
 
 # --------------------------------------------------------------------------------------------------
@@ -558,18 +738,19 @@ def test_batched_and_sequential_line_search_agree(fos):
 
 
 def test_lbfgs_boston_end_point(fos):
-    """Config-1 data through L-BFGS.  cond(A^T A) ~ 1e9: with a float32 gradient the PATH drifts from SciPy's float64
-    run in the middle iterations (curvature pairs are differences of noisy gradients; even two float64 codes differ
-    by 1e-5 there, tests/test_oracle_golden.py), the iteration count and the END POINT agree."""
+    """Config-1 data through L-BFGS.  cond(A^T A) ~ 1e9: the fp32 STORAGE rounding of A and b (6e-8 per entry) is a
+    perturbation the middle iterates amplify (even two float64 codes differ by 1e-5 there,
+    tests/test_oracle_golden.py); the first step, the iteration / evaluation counts and the END POINT agree."""
     fx = _data.load("boston")
     A, b = fx["boston/A"], fx["boston/b"]
     s = fos.LBFGSSolver("ridge", 0.0, 0.5).fit(A, b)
     # SURVEY 8(c) known answer of the reference for this call
     assert np.allclose(s.x_, [5.04537675, 0.14409563, -0.01939221, -0.05905357, 1.53772434], rtol=2e-4, atol=2e-5)
     assert s.final_obj_ == pytest.approx(2077.060367882381, rel=1e-6)
-    assert _data.rel(s.x_, fx["boston/lbfgs/enet_tiny1/x"]) < 1e-5
-    assert abs(s.nit_ - len(fx["boston/lbfgs/enet_tiny1/iterates"])) <= 2 and abs(s.nfev_ - 33) <= 4   # SURVEY 8c: 23 / 33
-    assert s.task_.startswith("CONVERGENCE")
+    assert _data.rel(s.x_, fx["boston/lbfgs/enet_tiny1/x"]) < TOL
+    nit_ref, nfev_ref = (int(v) for v in fx["boston/lbfgs/enet_tiny1/nit_nfev"])          # SURVEY 8c: 23 / 33
+    assert abs(s.nit_ - nit_ref) <= 1 and abs(s.nfev_ - nfev_ref) <= 2, (s.nit_, s.nfev_, s.task_)
+    assert s.task_ == "CONVERGENCE: REL_REDUCTION_OF_F_<=_FACTR*EPSMCH"
     assert _data.rel(s.iterates_[0], fx["boston/lbfgs/enet_tiny1/iterates"][0]) < 1e-6     # first step identical
 
 
@@ -656,7 +837,7 @@ def test_large_ragged_n_is_padded_onto_the_fused_path(fos):
     assert fos.estimate_lipschitz(prob) == pytest.approx(orc.estimate_lipschitz(A64, v0=v0), rel=TOL)
     s = fos.LBFGSSolver("ridge", 0.0, 1.0, max_iter=8).fit(prob, None)
     s_ref = orc.LBFGSSolver("ridge", 0.0, 1.0, max_iter=8).fit(A64, b64)
-    assert s.x_.shape == (n,) and _data.rel(s.x_, s_ref.x_) < 2e-5
+    assert s.x_.shape == (n,) and _data.rel(s.x_, s_ref.x_) < TOL and (s.nit_, s.nfev_) == (s_ref.nit_, s_ref.nfev_)
 
 
 @pytest.mark.parametrize("nlam", [2, 3, 4, 6])
@@ -844,5 +1025,16 @@ def test_tall_skinny_solvers_on_unstandardised_features(fos):
     x = fos.fista_delta(prob, None, "elasticnet", 1.0, 0.5, 3.0, max_iter=120, L=L)
     assert _data.rel(x, orc.fista_delta(A, b, "elasticnet", 1.0, 0.5, 3.0, max_iter=120, L=L)) < TOL
     s = fos.LBFGSSolver("ridge", 0.0, 0.5).fit(prob, None)
-    s_ref = orc.LBFGSSolver("ridge", 0.0, 0.5).fit(A, b)
-    assert _data.rel(s.x_, s_ref.x_) < 1e-4 and s.final_obj_ == pytest.approx(s_ref.final_obj_, rel=1e-6)
+    # cond(A^T A) ~ 1e9: the point at which the factr test stops the run is itself only determined to ~1e-5 (two
+    # float64 codes with different summation orders end 1e-5 apart, tests/test_oracle_golden.py), and the fp32 STORAGE
+    # rounding of A and b moves it by another ~2e-5.  Judged: the leading iterates at 1e-5 and the loss at 2e-8 against
+    # the oracle on exactly the stored data, the end point at 1e-4 against both oracles.
+    A32, b32 = A.astype(np.float32).astype(np.float64), b.astype(np.float32).astype(np.float64)
+    s_ref = orc.LBFGSSolver("ridge", 0.0, 0.5).fit(A32, b32)
+    for k in range(4):
+        assert _data.rel(s.iterates_[k], s_ref.iterates_[k]) < TOL, k
+    # (the factr test stops a run once a step lowers f by less than 2.2e-9 relative: the two end values may differ by that)
+    assert _data.rel(s.x_, s_ref.x_) < 1e-4 and s.final_obj_ == pytest.approx(s_ref.final_obj_, rel=2e-8)
+    assert abs(s.nit_ - s_ref.nit_) <= 2 and abs(s.nfev_ - s_ref.nfev_) <= 3, (s.nit_, s.nfev_, s_ref.nit_, s_ref.nfev_)
+    s_raw = orc.LBFGSSolver("ridge", 0.0, 0.5).fit(A, b)
+    assert _data.rel(s.x_, s_raw.x_) < 1e-4 and s.final_obj_ == pytest.approx(s_raw.final_obj_, rel=1e-6)
