@@ -90,11 +90,16 @@ def cpu_threads():
         return os.cpu_count() or 1
 
 
+SAMPLE_ROWS = 65536     # rows of the CPU-baseline / parity sample (the whole of cfg2; the first 65536 rows of cfg4 / cfg5)
+
+
 def cpu_baseline(cfg, A_dev, b_dev, a1, a2, L, x_gpu_k, k_check, budget_s=25.0):
-    """The oracle (NumPy fp64, all host cores through BLAS) on a bounded sample of the same workload."""
+    """The oracle (NumPy fp64, all host cores through BLAS) on a bounded sample of the same workload.  x_gpu_k: the
+    device's iterate after k_check iterations on the SAME sample (same rows, same L, alpha1, alpha2) - the parity
+    figure of the bench line is its relative distance to the oracle's iterate k_check."""
     from oracle import fos_oracle as orc
     m, n = cfg["m"], cfg["n"]
-    rows = min(m, 65536)
+    rows = min(m, SAMPLE_ROWS)
     t0 = time.perf_counter()
     A64 = A_dev[:rows].to(torch.float32).cpu().numpy().astype(np.float64)   # reference-native dtype (SURVEY 6)
     b64 = b_dev[:rows].cpu().numpy().astype(np.float64)
@@ -108,10 +113,10 @@ def cpu_baseline(cfg, A_dev, b_dev, a1, a2, L, x_gpu_k, k_check, budget_s=25.0):
     while True:
         prob.step(st)
         iters += 1
-        if rows == m and st.k == k_check and x_gpu_k is not None:
+        if st.k == k_check and x_gpu_k is not None:
             parity = float(np.linalg.norm(x_gpu_k - st.x) / max(np.linalg.norm(st.x), 1e-300))
         el = time.perf_counter() - t0
-        if (el > budget_s and iters >= 5) or iters >= 200:
+        if ((el > budget_s and iters >= 5) or iters >= 200) and (x_gpu_k is None or st.k >= k_check):
             break
     its = iters / el
     scale = rows / m
@@ -172,10 +177,20 @@ def run_workload(name, args, rank, world, device, steps, warmup, want_cpu, dist)
         torch.cuda.synchronize()
 
     do_steps(warmup)
-    x_check, k_check = None, warmup
-    if want_cpu:
-        x_check = eng.x().cpu().numpy()
-    eng.prob.profile(8)            # HIP events around every 8th launch of the dominant kernel
+    x_check, k_check = None, max(warmup, 3)
+    if want_cpu and rank == 0 and world == 1:
+        # Parity sample, outside the timed region: the same plan family on the rows the CPU baseline copies (all of
+        # cfg2; the first 65536 rows of cfg4 / cfg5), same L / alpha1 / alpha2, k_check iterations from x = 0.
+        rows = min(m, SAMPLE_ROWS)
+        sub = eng if rows == m and warmup == k_check else fd.HipShardEngine(A[:rows], b[:rows])
+        if sub is not eng:
+            sub.reset(tau=tau, alpha1=a1, alpha2=a2)
+            sub.st.run(k_check)
+        x_check = sub.x().cpu().numpy()
+        del sub
+    # HIP events around the launches of the dominant kernel: all of them for short runs, every 8th otherwise (the
+    # markers cost ~1 % when they bracket every launch of a long run)
+    eng.prob.profile(1 if steps <= 32 else 8)
     eng.prob.profile_read()
     fence()
     t0 = time.perf_counter()
@@ -204,7 +219,9 @@ def run_workload(name, args, rank, world, device, steps, warmup, want_cpu, dist)
     cpu, parity = None, None
     if want_cpu and rank == 0 and world == 1:
         cpu, parity = cpu_baseline(cfg, A, b, a1, a2, L, x_check, k_check)
-    res["cpu_baseline"], res["parity_rel_err"] = cpu, parity
+        assert parity is not None and parity < 1e-5, f"GPU iterate {k_check} differs from the oracle by {parity}: invalid run"
+    res["cpu_baseline"], res["parity_rel_err"], res["parity_k"] = cpu, parity, k_check
+    res["parity_rows"] = min(m, SAMPLE_ROWS)
     del solver, eng, matvec_prob, A, b
     torch.cuda.empty_cache()
     return res
@@ -328,6 +345,9 @@ def main():
             "roofline": roofline_obj(res, name if world == 1 else None),
             "cpu_baseline": res["cpu_baseline"],
             "parity_rel_err_vs_cpu_at_warmup_iterate": res["parity_rel_err"],
+            "parity": {"rel_err": res["parity_rel_err"], "iterate": res["parity_k"], "rows": res["parity_rows"],
+                       "what": "||x_gpu - x_oracle|| / ||x_oracle|| after `iterate` iterations from x = 0 on the first "
+                               "`rows` rows of this workload (same L, alpha1, alpha2); the run aborts above 1e-5"},
             "lipschitz_power_iteration_s": res["lipschitz_s"],
             "target_ref": target_ref,
         }

@@ -157,6 +157,20 @@ class Problem:
         plan["tall"] = (flags >> 2) & 1           # n <= 64: row-per-thread single pass (any alignment)
         return plan
 
+    def replan(self, no_resident=False, no_tall=False, no_wide=False):
+        """Re-run the planner with kernel families switched off (fos_problem_replan): tests and A/B measurements.
+        Call before creating Fista handles on this problem."""
+        flags = ((_lib.PLAN_NO_RESIDENT if no_resident else 0) | (_lib.PLAN_NO_TALL if no_tall else 0) |
+                 (_lib.PLAN_NO_WIDE if no_wide else 0))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fos_problem_replan(self.h, flags), "fos_problem_replan")
+
+    def set_comm(self, comm):
+        """Attach a `distributed.Comm` (or None): this problem's rows are one shard of a row-sharded problem and every
+        row-sum is all-reduced on the stream (fos_problem_set_comm)."""
+        _lib.check(self.lib.fos_problem_set_comm(self.h, comm.h if comm is not None else None), "fos_problem_set_comm")
+        self.comm = comm               # keeps the communicator alive as long as the problem
+
     def tune(self, threads, chunks, rows, workgroups=0):
         _lib.check(self.lib.fos_problem_tune(self.h, threads, chunks, rows, workgroups), "fos_problem_tune")
 

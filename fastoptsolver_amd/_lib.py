@@ -10,6 +10,7 @@ FOS_F32, FOS_BF16 = 0, 1
 MODE_FISTA, MODE_DELTA, MODE_ISTA = 0, 1, 2
 PROX_L1, PROX_ENET = 0, 1
 STOP_NONE, STOP_STEP, STOP_RATIO, STOP_GRAD = 0, 1, 2, 3
+PLAN_NO_RESIDENT, PLAN_NO_TALL, PLAN_NO_WIDE = 1, 2, 4
 
 
 class FistaParams(C.Structure):
@@ -38,6 +39,14 @@ SIGNATURES = {
     "fos_problem_plan": (_i32, [_vp, C.POINTER(C.c_int32)]),
     "fos_problem_tune": (_i32, [_vp, _i32, _i32, _i32, _i32]),
     "fos_problem_set_gbuf": (_i32, [_vp, _vp]),
+    "fos_problem_replan": (_i32, [_vp, C.c_uint]),
+    "fos_comm_unique_id": (_i32, [C.c_char_p]),
+    "fos_comm_create": (_i32, [C.POINTER(_vp), C.c_char_p, _i32, _i32]),
+    "fos_comm_destroy": (_i32, [_vp]),
+    "fos_comm_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "fos_comm_transport": (C.c_char_p, []),
+    "fos_comm_allreduce": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "fos_problem_set_comm": (_i32, [_vp, _vp]),
     "fos_problem_profile": (_i32, [_vp, _i32]),
     "fos_problem_profile_read": (_i32, [_vp, C.POINTER(_f64), C.POINTER(_i64)]),
     "fos_gemv_pair": (_i32, [_vp, _vp, _f32, _vp, _vp]),

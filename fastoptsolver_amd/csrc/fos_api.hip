@@ -12,6 +12,7 @@
 
 #include "../../include/fos.h"
 #include "batch_trial.hpp"
+#include "comm.hpp"
 #include "gemv_multi.hpp"
 #include "gemv_pair.hpp"
 #include "gemv_tall.hpp"
@@ -225,6 +226,9 @@ struct fos_problem {
   int dtype = FOS_F32;
   hipStream_t stream = nullptr;
   int ncu = 256;
+  fos_comm* comm = nullptr;          // row-sharded problem: sums of partial results go through it (comm.hpp)
+  unsigned plan_flags = 0;           // FOS_PLAN_* given to fos_problem_replan
+  bool allow_resident = true;
   // plan
   int path = 0;                      // 0 fused, 1 two-pass fallback
   bool resident = false;             // small enough for the single-launch LDS-resident loop (resident.hpp)
@@ -426,7 +430,33 @@ int launch_pass_inner(fos_problem* p, const YSource& ys, const float* b, bool wi
   return FOS_OK;
 }
 
+// Sum `count` floats / doubles over the ranks of a sharded problem, in place, on the handle's stream (no-op otherwise).
+int reduce_across(fos_problem* p, void* buf, size_t count, bool f64) {
+  if (!p->comm) return FOS_OK;
+  const ncclResult_t r = p->comm->api->AllReduce(buf, buf, count, f64 ? ncclDouble : ncclFloat, ncclSum, p->comm->nccl, p->stream);
+  if (r != ncclSuccess) return fail(FOS_ERR_HIP, std::string("ncclAllReduce: ") + p->comm->api->GetErrorString(r));
+  return FOS_OK;
+}
+
+__global__ void rr_from_gbuf_kernel(const float* __restrict__ gbuf, int n, double* __restrict__ rr_out, const int* stopped) {
+  if (stopped != nullptr && *stopped != 0) return;
+  *rr_out = (double)gbuf[n];
+}
+
+int launch_slab_reduce_local(fos_problem* p, int n_rr, float* gbuf, double* rr_out, const int* stopped);
+// slabs -> gbuf[0..n], summed over the ranks when the problem is sharded; rr_out (nullable) = the global ||r||^2
 int launch_slab_reduce(fos_problem* p, int n_rr, float* gbuf, double* rr_out, const int* stopped) {
+  int rc = launch_slab_reduce_local(p, n_rr, gbuf, rr_out, stopped);
+  if (rc || !p->comm) return rc;
+  if ((rc = reduce_across(p, gbuf, (size_t)p->n + 1, false))) return rc;
+  if (rr_out != nullptr) {
+    hipLaunchKernelGGL(rr_from_gbuf_kernel, dim3(1), dim3(1), 0, p->stream, gbuf, (int)p->n, rr_out, stopped);
+    LAUNCH_CHECK();
+  }
+  return FOS_OK;
+}
+
+int launch_slab_reduce_local(fos_problem* p, int n_rr, float* gbuf, double* rr_out, const int* stopped) {
   const int grid = (int)((p->n + fos::RCOLS - 1) / fos::RCOLS);
   if (p->vec4)
     hipLaunchKernelGGL(fos::slab_reduce_kernel<true>, dim3(grid), dim3(256), 0, p->stream, p->slabs, p->nslabs,
@@ -498,7 +528,7 @@ int launch_residual_batch(fos_problem* p, int use_b, double* out16) {
   if ((rc = prof_mark(p, false))) return rc;
   hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->q_part, (int)nwg, fos::BT_NV, out16);
   LAUNCH_CHECK();
-  return FOS_OK;
+  return reduce_across(p, out16, fos::BT_NV, true);      // sharded: ||A dlt_j||^2 = sum over the row blocks
 }
 
 // ---- multi-lambda lockstep run ----------------------------------------------------------------------------------
@@ -530,6 +560,25 @@ int aligned_vec(fos_problem* p, const float* v, const float** out) {
   HIP_TRY(hipMemcpyAsync(p->ybuf, v, (size_t)p->n * sizeof(float), hipMemcpyDeviceToDevice, p->stream));
   *out = p->ybuf;
   return FOS_OK;
+}
+
+// Choose the kernel family for this problem; `flags` (FOS_PLAN_*) switch individual families off (fos_problem_replan).
+void apply_plan(fos_problem* p, unsigned flags) {
+  const int64_t m = p->m, n = p->n;
+  p->plan_flags = flags;
+  p->tall = false;
+  p->slab_stride = 0;
+  p->vec4 = (n % 4 == 0);
+  p->allow_resident = !(flags & FOS_PLAN_NO_RESIDENT);
+  p->resident = fos::resident_fits(m, n) && p->allow_resident && p->comm == nullptr;
+  const int epc = epc_of(p->dtype);
+  const bool vec_ok = (n % epc == 0) && (p->lda % epc == 0) && ((reinterpret_cast<uintptr_t>(p->A) & 15u) == 0);
+  const MenuEntry* e = vec_ok ? default_entry(p->dtype, n) : nullptr;
+  if (n <= fos::TL_MAX_N && !(flags & FOS_PLAN_NO_TALL))
+    plan_tall(p, tall_entry(p->dtype, n, p->lda, p->A));
+  else if (e) plan_fused(p, e, 0);
+  else if (vec_ok && p->dtype == FOS_F32 && n <= fos::WD_MAX_N && !(flags & FOS_PLAN_NO_WIDE)) plan_fused(p, &kWideF32, 0);
+  else plan_fallback(p);
 }
 
 // ---- fp64-accumulating pass (L-BFGS fg) -----------------------------------------------------------------------------
@@ -592,16 +641,7 @@ int fos_problem_create(fos_problem** out, const void* A, int64_t m, int64_t n, i
     return fail(FOS_ERR_HIP, "fos_problem_create: no HIP device");
   }
   p->ncu = prop.multiProcessorCount;
-  p->vec4 = (n % 4 == 0);
-  p->resident = fos::resident_fits(m, n) && getenv("FOS_NO_RESIDENT") == nullptr;
-  const int epc = epc_of(a_dtype);
-  const bool vec_ok = (n % epc == 0) && (lda % epc == 0) && ((reinterpret_cast<uintptr_t>(A) & 15u) == 0);
-  const MenuEntry* e = vec_ok ? default_entry(a_dtype, n) : nullptr;
-  if (n <= fos::TL_MAX_N && getenv("FOS_NO_TALL") == nullptr)
-    plan_tall(p, tall_entry(a_dtype, n, lda, A));
-  else if (e) plan_fused(p, e, 0);
-  else if (vec_ok && a_dtype == FOS_F32 && n <= fos::WD_MAX_N && getenv("FOS_NO_WIDE") == nullptr) plan_fused(p, &kWideF32, 0);
-  else plan_fallback(p);
+  apply_plan(p, 0);
   int rc = ensure_workspace(p);
   if (rc == FOS_OK) {
     hipError_t he = hipMalloc(&p->gbuf_own, (size_t)(n + 4) * sizeof(float));
@@ -618,6 +658,91 @@ int fos_problem_create(fos_problem** out, const void* A, int64_t m, int64_t n, i
   }
   *out = p;
   return FOS_OK;
+}
+
+// ---- communicator (comm.hpp) ------------------------------------------------------------------------------------
+int fos_comm_unique_id(char id[128]) {
+  if (!id) return fail(FOS_ERR_ARG, "fos_comm_unique_id: null");
+  std::string err;
+  const fos::RcclApi* api = fos::rccl_api(&err);
+  if (!api) return fail(FOS_ERR_UNSUPPORTED, err);
+  ncclUniqueId uid;
+  const ncclResult_t r = api->GetUniqueId(&uid);
+  if (r != ncclSuccess) return fail(FOS_ERR_HIP, std::string("ncclGetUniqueId: ") + api->GetErrorString(r));
+  static_assert(sizeof(uid) == 128, "ncclUniqueId is 128 bytes");
+  std::memcpy(id, &uid, sizeof(uid));
+  return FOS_OK;
+}
+
+int fos_comm_create(fos_comm** out, const char id[128], int nranks, int rank) {
+  if (!out || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(FOS_ERR_ARG, "fos_comm_create: bad argument");
+  std::string err;
+  const fos::RcclApi* api = fos::rccl_api(&err);
+  if (!api) return fail(FOS_ERR_UNSUPPORTED, err);
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  fos_comm* c = new fos_comm();
+  c->nranks = nranks; c->rank = rank; c->api = api;
+  const ncclResult_t r = api->CommInitRank(&c->nccl, nranks, uid, rank);
+  if (r != ncclSuccess) {
+    delete c;
+    return fail(FOS_ERR_HIP, std::string("ncclCommInitRank: ") + api->GetErrorString(r));
+  }
+  *out = c;
+  return FOS_OK;
+}
+
+int fos_comm_destroy(fos_comm* c) {
+  if (!c) return FOS_OK;
+  if (c->nccl) (void)c->api->CommDestroy(c->nccl);
+  delete c;
+  return FOS_OK;
+}
+
+int fos_comm_info(const fos_comm* c, int* nranks, int* rank) {
+  if (!c) return fail(FOS_ERR_ARG, "fos_comm_info: null");
+  if (nranks) *nranks = c->nranks;
+  if (rank) *rank = c->rank;
+  return FOS_OK;
+}
+
+const char* fos_comm_transport(void) {
+  static std::string text;
+  std::string err;
+  const fos::RcclApi* api = fos::rccl_api(&err);
+  text = api ? ("rccl: " + api->origin) : ("none: " + err);
+  return text.c_str();
+}
+
+int fos_comm_allreduce(fos_comm* c, void* buf, int64_t count, int is_f64, void* stream) {
+  if (!c || !buf || count < 0) return fail(FOS_ERR_ARG, "fos_comm_allreduce: bad argument");
+  const ncclResult_t r = c->api->AllReduce(buf, buf, (size_t)count, is_f64 ? ncclDouble : ncclFloat, ncclSum, c->nccl,
+                                           (hipStream_t)stream);
+  if (r != ncclSuccess) return fail(FOS_ERR_HIP, std::string("ncclAllReduce: ") + c->api->GetErrorString(r));
+  return FOS_OK;
+}
+
+int fos_problem_set_comm(fos_problem* p, fos_comm* c) {
+  if (!p) return fail(FOS_ERR_ARG, "fos_problem_set_comm: null");
+  p->comm = c;
+  if (c) p->resident = false;        // the one-workgroup resident loop has no exchange step
+  else p->resident = fos::resident_fits(p->m, p->n) && p->allow_resident;
+  return FOS_OK;
+}
+
+int fos_problem_replan(fos_problem* p, unsigned flags) {
+  if (!p) return fail(FOS_ERR_ARG, "fos_problem_replan: null");
+  if (flags & ~(unsigned)(FOS_PLAN_NO_RESIDENT | FOS_PLAN_NO_TALL | FOS_PLAN_NO_WIDE))
+    return fail(FOS_ERR_ARG, "fos_problem_replan: unknown flag");
+  // workspace sized for the old plan (slab stride, fp64 slabs) is dropped and rebuilt
+  void* drop[] = {p->slabs, p->rr_part, p->rr2_part, p->slabs_dd, p->rr_dd};
+  for (void* q : drop)
+    if (q) (void)hipFree(q);
+  p->slabs = nullptr; p->rr_part = p->rr2_part = nullptr; p->slabs_dd = nullptr; p->rr_dd = nullptr;
+  p->slab_cap = p->rr_cap = 0;
+  p->dd_entry = nullptr; p->dd_two_pass_chunks = 0;
+  apply_plan(p, flags);
+  return ensure_workspace(p);
 }
 
 int fos_problem_profile(fos_problem* p, int enable) {
@@ -763,10 +888,12 @@ int fos_gemv_pair_dd(fos_problem* p, const double* x, double alpha2, double* gra
   }
   LAUNCH_CHECK();
   if ((rc = prof_mark(p, false))) return rc;
+  // sharded: alpha2*x enters the sum over the ranks exactly once (rank 0 adds it to its partial)
+  const double a2_here = (p->comm && p->comm->rank != 0) ? 0.0 : alpha2;
   hipLaunchKernelGGL(fos::slab_reduce_dd_kernel, dim3((unsigned)((p->n + 127) / 128)), dim3(256), 0, p->stream, p->slabs_dd,
-                     nslabs, (int)p->n, stride, p->rr_dd, n_rr, alpha2, x, grad_rr);
+                     nslabs, (int)p->n, stride, p->rr_dd, n_rr, a2_here, x, grad_rr);
   LAUNCH_CHECK();
-  return FOS_OK;
+  return reduce_across(p, grad_rr, (size_t)p->n + 1, true);
 }
 
 int fos_residual_objective(fos_problem* p, const float* x, double* out3) {
@@ -778,6 +905,8 @@ int fos_residual_objective(fos_problem* p, const float* x, double* out3) {
   int n_rr = 0;
   if ((rc = launch_pass(p, ys, p->b, false, &n_rr))) return rc;
   hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->rr_part, n_rr, 1, out3);
+  LAUNCH_CHECK();
+  if ((rc = reduce_across(p, out3, 1, true))) return rc;
   hipLaunchKernelGGL(fos::vec_norms_kernel, dim3(1), dim3(fos::LB_THREADS), 0, p->stream, xa, p->n, out3 + 1);
   LAUNCH_CHECK();
   return FOS_OK;
@@ -1103,7 +1232,7 @@ int fos_fista_run_history(fos_fista* f, int iters, double* x_hist, double* hist,
     return fail(FOS_ERR_ARG, "fos_fista_run_history: bad argument");
   fos_problem* p = f->p;
   if (plain_run(f) && p->resident) return iters == 0 ? FOS_OK : run_resident(f, iters, x_hist, hist);
-  if (!plain_run(f) || p->path != 0 || p->entry->dual == nullptr)
+  if (!plain_run(f) || p->path != 0 || p->entry->dual == nullptr || p->comm != nullptr)
     return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_history: needs a plain run on the fused path with a DUAL kernel");
   if (iters == 0) return FOS_OK;
   bool stopped = false;
@@ -1158,6 +1287,17 @@ int fos_fista_run(fos_fista* f, int iters) {
   fos_problem* p = f->p;
   if (iters == 0) return FOS_OK;
   if (p->resident) return run_resident(f, iters, nullptr, nullptr);
+  if (p->comm) {
+    // Row-sharded problem: K2 on this rank's rows -> slab reduction -> all-reduce of [gradient ; ||r||^2] (n + 1 floats)
+    // -> prox + momentum from the reduced gradient, all enqueued on one stream; every rank applies the identical fp64
+    // update to identical numbers, so the replicated iterates stay bit-identical.
+    for (int it = 0; it < iters; ++it) {
+      int rc;
+      if ((rc = fos_fista_grad(f))) return rc;
+      if ((rc = fos_fista_update(f))) return rc;
+    }
+    return flush_pending(f);
+  }
   // Plain run: no data-dependent control (adaptive restart / stopping tolerances).  t_k and beta_k are then a fixed
   // sequence: the host passes beta_k to both kernels by value, and the scalar bookkeeping kernel runs once per call
   // instead of once per iteration (two launches per iteration instead of three).
@@ -1207,7 +1347,7 @@ int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters) {
     if (!fs[v] || fs[v]->p != fs[0]->p) return fail(FOS_ERR_ARG, "fos_fista_run_multi: handles must share one problem");
   if (nv == 1) return fos_fista_run(fs[0], iters);
   fos_problem* p = fs[0]->p;
-  MultiLaunch fn = (p->path == 0 && !p->tall && p->dtype == FOS_F32) ? find_multi(p->n, nv) : nullptr;
+  MultiLaunch fn = (p->path == 0 && !p->tall && p->dtype == FOS_F32 && !p->comm) ? find_multi(p->n, nv) : nullptr;
   for (int v = 0; v < nv && fn; ++v)
     if (!plain_run(fs[v])) fn = nullptr;
   if (!fn) return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_multi: no multi-vector kernel for this shape / configuration");
@@ -1299,7 +1439,7 @@ int fos_fista_grad_dual(fos_fista* f) {
     hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->rr2_part, n_rr, 1,
                        &f->scal->rr_x);
     LAUNCH_CHECK();
-    return FOS_OK;
+    return reduce_across(p, &f->scal->rr_x, 1, true);
   }
   // no DUAL instantiation (fallback path / wide geometries): a separate residual pass on x_k, then the gradient
   hipLaunchKernelGGL(fos::cast_f64_f32_kernel, dim3(grid_1d(p->n, 256, 1024)), dim3(256), 0, p->stream, f->x_cur, p->ybuf,
@@ -1310,6 +1450,7 @@ int fos_fista_grad_dual(fos_fista* f) {
   hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->rr_part, n_rr, 1,
                      &f->scal->rr_x);
   LAUNCH_CHECK();
+  if ((rc = reduce_across(p, &f->scal->rr_x, 1, true))) return rc;
   return fos_fista_grad(f);
 }
 
@@ -1370,6 +1511,7 @@ int fos_fista_trial(fos_fista* f, double t, int with_residual, double out8[8]) {
     if ((rc = launch_pass(p, ys, nullptr, false, &n_rr))) return rc;        // ||A dlt||^2  (b = 0)
     hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->rr_part, n_rr, 1, f->out5 + 5);
     LAUNCH_CHECK();
+    if ((rc = reduce_across(p, f->out5 + 5, 1, true))) return rc;
   }
   HIP_TRY(hipMemcpyAsync(out8, f->out5, 8 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));

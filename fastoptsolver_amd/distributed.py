@@ -13,11 +13,13 @@ The class is written against a small "engine" interface (grad / gbuf / update / 
 choreography is tested on CPU with gloo and a stand-in engine (tests/test_distributed_cpu.py); the product
 engine below drives the HIP kernels and has no CPU fallback.
 """
+import ctypes as C
 import math
 
+import torch
 import torch.distributed as dist
 
-from . import _core
+from . import _core, _lib
 
 
 def shard_rows(m, world, rank):
@@ -27,17 +29,87 @@ def shard_rows(m, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-class HipShardEngine:
-    """The product engine: this rank's rows on this rank's GPU."""
+class Comm:
+    """Communicator under the C ABI (fos_comm_*: RCCL over xGMI): attached to a Problem it makes every row-sum of that
+    problem a sum over the ranks, on the problem's stream - sharded runs then enqueue like single-GPU ones.
 
-    def __init__(self, A_shard, b_shard, dtype=None):
-        self.prob = _core.Problem(A_shard, b_shard, dtype)
+    ``Comm(group)`` is collective over the ranks of a torch.distributed group (any backend: it only carries the 128-byte
+    id from rank 0 to the others); the current device must be this rank's GPU.  ``Comm.solo()`` is a one-rank
+    communicator that needs no process group (the all-reduce path on a single GPU: tests, rehearsals)."""
+
+    def __init__(self, group=None, _solo=False):
+        self.lib = _lib.load()
+        _core.require_gpu()
+        if _solo:
+            world, rank = 1, 0
+        else:
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+        ids = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            _lib.check(self.lib.fos_comm_unique_id(buf), "fos_comm_unique_id")
+            ids[0] = buf.raw
+        if world > 1:
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(ids, src=src, group=group)
+        h = C.c_void_p()
+        _lib.check(self.lib.fos_comm_create(C.byref(h), ids[0], world, rank), "fos_comm_create")
+        self.h, self.world, self.rank = h, world, rank
+
+    @classmethod
+    def solo(cls):
+        return cls(_solo=True)
+
+    def transport(self):
+        return self.lib.fos_comm_transport().decode()
+
+    def allreduce(self, t):
+        """In-place sum of a float32 / float64 device tensor over the ranks, on the current stream."""
+        assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.float64)
+        _lib.check(self.lib.fos_comm_allreduce(self.h, _core.ptr(t), t.numel(), int(t.dtype == torch.float64),
+                                               _core.stream_ptr()), "fos_comm_allreduce")
+        return t
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h:
+            try:
+                self.lib.fos_comm_destroy(h)
+            except Exception:
+                pass
+            self.h = None
+
+
+class HipShardEngine:
+    """The product engine: this rank's rows on this rank's GPU.
+
+    ``comm``: a `Comm` -> the all-reduce happens under the C ABI, on the problem's stream (`run(k)` enqueues k whole
+    iterations).  Without it the engine exposes the split step (grad / gbuf / update) and `ShardedFista` moves gbuf
+    through torch.distributed between the two halves (any backend; what the gloo tests use).
+    Columns are always padded to the kernel granularity here (pad=True), so every rank derives the same device length
+    n_dev from n alone, whatever its local row count or pointer alignment - the all-reduce count must agree."""
+
+    def __init__(self, A_shard, b_shard, dtype=None, comm=None, group=None):
+        self.prob = _core.Problem(A_shard, b_shard, dtype, pad=True)
         self.n = self.prob.n_dev             # device length: gbuf[n_dev] carries the partial ||r||^2
+        self.comm = comm
+        if comm is not None:
+            self.prob.set_comm(comm)
+        if group is not None and dist.is_initialized() and dist.get_world_size(group) > 1:
+            probe = torch.tensor([self.n, -self.n], dtype=torch.int64,
+                                 device=self.prob.device if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(probe, op=dist.ReduceOp.MAX, group=group)
+            if int(probe[0]) != self.n or int(-probe[1]) != self.n:
+                raise ValueError("row shards disagree on the device length of the column dimension")
         self.st = _core.Fista(self.prob)
         self.gbuf = self.prob.gbuf            # torch tensor (n + 4 floats) the kernels write / read
 
     def reset(self, **kw):
         self.st.reset(**kw)
+
+    def run(self, iters):
+        """comm attached: `iters` whole sharded iterations, enqueue-only (fos_fista_run)."""
+        self.st.run(iters)
 
     def grad(self):
         self.st.grad()
@@ -62,12 +134,18 @@ class ShardedFista:
 
     def step(self):
         e = self.engine
+        if getattr(e, "comm", None) is not None:                  # exchange under the C ABI, on the kernels' stream
+            e.run(1)
+            return
         e.grad()                                                  # partial A_p^T (A_p y - b_p), partial rr
         if self.world > 1:
             dist.all_reduce(e.gbuf[: e.n + 1], op=dist.ReduceOp.SUM, group=self.group)
         e.update()                                                # identical on every rank
 
     def run(self, iters):
+        if getattr(self.engine, "comm", None) is not None:
+            self.engine.run(int(iters))
+            return
         for _ in range(int(iters)):
             self.step()
 

@@ -81,13 +81,44 @@ class _EventTimer:
 # ---------------------------------------------------------------------
 # Estimate Lipschitz constant L = λ_max(AᵀA)                    ref:45-60
 # ---------------------------------------------------------------------
-def estimate_lipschitz(A, n_iter: int = 100, tol: float = 1e-6) -> float:
+def estimate_lipschitz(A, n_iter: int = 100, tol: float = 1e-6, *, group=None) -> float:
     """Power iteration on the device (w = Aᵀ(Av) is the single-pass GEMV-pair kernel with b = 0).
-    Draws ``np.random.randn(n)`` from the global legacy stream exactly like ref:50."""
+    Draws ``np.random.randn(n)`` from the global legacy stream exactly like ref:50.
+
+    Row-sharded problems: with a ``Comm`` attached to the problem the kernels' all-reduce makes this the power
+    iteration of the whole matrix as it stands; ``group=`` (a torch.distributed group, split-form sharding) sums
+    w over the ranks here.  Every rank must draw the same v0 (seed the global stream identically)."""
     prob = _core.prepare(A)
     v0 = np.random.randn(prob.n)
+    if group is not None:
+        from .distributed import sharded_lipschitz
+        bare = prob if prob.b is None else _core.Problem(prob.A, None, prob.dtype, pad=False)   # same A, b = 0 (ref:54)
+        return sharded_lipschitz(lambda v: bare.gemv_pair(v, 0.0), prob.n, prob.vec_in(v0)[: prob.n], n_iter, tol,
+                                 group=group)
     L, _, _ = prob.power_iter(v0, n_iter=n_iter, tol=tol)
     return L
+
+
+class _GroupReducer:
+    """Split-form sharding over a torch.distributed group (any backend): the sums over row blocks that the device
+    would do itself with a Comm attached are done here, between the kernels, in the order every rank follows."""
+
+    def __init__(self, prob, group):
+        import torch.distributed as dist
+        self.dist, self.group, self.prob = dist, group, prob
+        self.on_device = dist.get_backend(group) == "nccl"
+
+    def grad(self):
+        """[partial gradient ; partial ||r||^2] -> global, in gbuf (n + 1 floats: the one exchange per iteration)."""
+        self.dist.all_reduce(self.prob.gbuf[: self.prob.n_dev + 1], op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def rr_global(self):
+        return float(self.prob.gbuf[self.prob.n_dev])
+
+    def sum(self, vals):
+        t = torch.tensor(list(vals), dtype=torch.float64, device=self.prob.device if self.on_device else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.tolist()
 
 
 # ---------------------------------------------------------------------
@@ -118,16 +149,18 @@ def _armijo_accepts(tr, t_k, smooth_a2):
 def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backtracking=False, eta=0.5,
            max_iter=500, tol=0.0, tol_ratio=0.0, adaptive_restart=False, restart_threshold=1.0,
            grad_tol_check=False, history=None, history_obj=None, x0=None, check_every=None, log=None,
-           batch_trials=True):
+           batch_trials=True, reducer=None, state=None):
     """Run the state machine.  Device-driven when nothing needs a per-iteration host decision,
     host-driven otherwise (grad-norm stop ref:179, backtracking ref:183-197, history ref:224-232)."""
-    st = _core.Fista(prob)
+    st = state if state is not None else _core.Fista(prob)      # `state`: a stand-in with the same interface (CPU tests)
     x0_dev = None if x0 is None else _core.to_device_vec(x0, prob.device).double()   # padded by Fista.reset
     st.reset(tau, alpha1, alpha2, mode=mode, prox_kind=prox_kind, delta=delta, adaptive_restart=adaptive_restart,
              restart_threshold=restart_threshold, tol_step=tol if tol > 0.0 else 0.0,
              tol_ratio=tol_ratio if tol_ratio > 0.0 else 0.0, x0=x0_dev)
     gtimer = _EventTimer(grad_call_times)
-    host_driven = backtracking or history is not None or log is not None or (grad_tol_check and tol > 0.0)
+    # reducer: split-form sharding - the all-reduce sits between the gradient and the update, so the host drives
+    host_driven = (backtracking or history is not None or log is not None or (grad_tol_check and tol > 0.0)
+                   or reducer is not None)
     smooth_a2 = alpha2 if (prox_kind == _lib.PROX_L1 and alpha2 > 0) else 0.0
     use_batch = batch_trials
 
@@ -152,7 +185,7 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
 
     # Small problems (A fits one CU's LDS): every host-driven feature - backtracking, gradient-norm stop, history, ISTA
     # log - runs inside ONE launch of the LDS-resident loop; the host only unpacks what the device recorded.
-    if max_iter > 0:
+    if max_iter > 0 and reducer is None:
         ev = gtimer.start()
         ls_t0 = time.perf_counter()
         res = st.run_resident(max_iter, backtracking=backtracking, eta=eta, armijo_c=C,
@@ -187,7 +220,7 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
     # History without any per-iteration host round trip: x and the objective ingredients are recorded on the device
     # by the same two kernels of the plain run and read back once (ref:224-232, :319-322).
     plain = not (mode == _lib.MODE_FISTA and adaptive_restart) and tol == 0.0 and tol_ratio == 0.0
-    if history is not None and log is None and not backtracking and plain and max_iter > 0:
+    if history is not None and log is None and not backtracking and plain and max_iter > 0 and reducer is None:
         chunk = max(1, min(max_iter, _HISTORY_CHUNK_BYTES // (8 * prob.n_dev)))     # bound the device-side x history
         done, supported = 0, True
         while done < max_iter and supported:
@@ -214,15 +247,20 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
     # History objective f(x_k) without the reference's extra pass per iteration (ref:225-230, :321): the DUAL
     # gradient pass of iteration k also returns ||A x_k - b||^2, so f(x_k) is appended one iteration late and only
     # the very last iterate needs a residual pass of its own.
+    def rr_x_of(status):         # ||A x_k - b||^2 over ALL rows (split-form sharding: summed here)
+        return reducer.sum([status.rr_x])[0] if reducer is not None else status.rr_x
+
     owed = None                  # (||x||_1, ||x||_2^2) of the newest iterate whose objective is not recorded yet
     for _ in range(max_iter):
         ev = gtimer.start()
         st.grad(dual=owed is not None)                        # ref:173-175 (alpha2*y is added by the consumers)
+        if reducer is not None:
+            reducer.grad()
         gtimer.stop(ev)
         if grad_tol_check and tol > 0.0:                      # ref:179
             if math.sqrt(st.trial(tau, with_residual=False)["gnorm2"]) < tol:
                 if owed is not None:
-                    history["obj"].append(history_obj(st.status().rr_x, owed[1], owed[0]))
+                    history["obj"].append(history_obj(rr_x_of(st.status()), owed[1], owed[0]))
                     owed = None
                 break
         if backtracking:                                      # ref:183-197 / ref:298-312 / ref:92-108
@@ -237,6 +275,10 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
                 if rows is None:
                     use_batch = False
                     rows = [st.trial(t_k, with_residual=True)]
+                if reducer is not None:                        # ||A dlt||^2 = sum over the row blocks; ||r||^2 likewise
+                    for tr, q in zip(rows, reducer.sum([tr["q"] for tr in rows])):
+                        tr["q"] = q
+                        tr["rr_y"] = reducer.rr_global()
                 for tr in rows:
                     if _armijo_accepts(tr, t_k, smooth_a2):
                         accepted = True
@@ -253,7 +295,7 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
             s = st.status()
             if history is not None:
                 if owed is not None:
-                    history["obj"].append(history_obj(s.rr_x, owed[1], owed[0]))
+                    history["obj"].append(history_obj(rr_x_of(s), owed[1], owed[0]))
                 history["x"].append(_core.from_device_vec(xk, like))
                 owed = (s.xnorm1, s.xnorm2)
             if log is not None:
@@ -266,6 +308,8 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
             break
     if owed is not None:
         rr, x2, x1 = prob.residual_objective(st.x_tensor())
+        if reducer is not None:
+            rr = reducer.sum([rr])[0]
         history["obj"].append(history_obj(rr, x2, x1))
     gtimer.flush()
     return st
@@ -388,17 +432,37 @@ def ista(x0, g, grad_g, prox_h, L, backtracking: bool = False, eta: float = 0.5,
     return (out, log) if return_history else out
 
 
+def _sharded_problem(A, b, dtype, comm, group):
+    """(problem, reducer) for the solver front-ends: plain, Comm-attached (reductions under the C ABI, reducer None)
+    or split-form over a torch.distributed group (reducer does the sums)."""
+    if comm is None and group is None:
+        return _core.as_problem(A, b, dtype), None
+    import torch.distributed as dist
+    prob = A if isinstance(A, _core.Problem) else _core.Problem(A, b, dtype, pad=True)   # same n_dev on every rank
+    if comm is not None:
+        if getattr(prob, "comm", None) is not comm:
+            prob.set_comm(comm)
+        return prob, None
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return prob, None
+    return prob, _GroupReducer(prob, group)
+
+
 # ---------------------------------------------------------------------
 # FISTA                                                        ref:132-245
 # ---------------------------------------------------------------------
 def fista(A, b, reg_type: str, alpha1: float, alpha2: float, backtracking: bool = False, eta: float = 0.5,
           t_init_factor: float = 1.0, max_iter: int = 500, tol: float = 0.0, tol_ratio: float = 0.0,
           adaptive_restart: bool = False, restart_threshold: float = 1.0, return_history: bool = False,
-          *, L=None, dtype=None, check_every=None):
+          *, L=None, dtype=None, check_every=None, comm=None, group=None):
+    """``comm=`` / ``group=``: A, b are THIS RANK's rows of a row-sharded problem (one process per GPU); every flag
+    of the reference's loop works sharded - backtracking, history, restart, the stopping rules.  ``comm`` (a
+    `distributed.Comm`) puts the one all-reduce per iteration on the kernels' stream under the C ABI; ``group`` (a
+    torch.distributed group, any backend) does it between the kernels from Python."""
     reset_metrics()
-    prob = _core.as_problem(A, b, dtype)
+    prob, reducer = _sharded_problem(A, b, dtype, comm, group)
     like = prob.like
-    L_val = estimate_lipschitz(prob) if L is None else float(L)               # ref:155
+    L_val = estimate_lipschitz(prob, group=group if reducer is not None else None) if L is None else float(L)   # ref:155
     if alpha2 > 0:                                                            # ref:156-157
         L_val += alpha2
     tau = t_init_factor / L_val                                               # ref:158
@@ -409,7 +473,8 @@ def fista(A, b, reg_type: str, alpha1: float, alpha2: float, backtracking: bool 
     st = _drive(prob, like, mode=_lib.MODE_FISTA, prox_kind=_lib.PROX_L1, alpha1=alpha1, alpha2=alpha2, tau=tau,
                 backtracking=backtracking, eta=eta, max_iter=max_iter, tol=tol, tol_ratio=tol_ratio,
                 adaptive_restart=adaptive_restart, restart_threshold=restart_threshold, grad_tol_check=True,
-                history=history, history_obj=_objective_by_alpha(alpha1, alpha2), check_every=check_every)
+                history=history, history_obj=_objective_by_alpha(alpha1, alpha2), check_every=check_every,
+                reducer=reducer)
     x_k = _core.from_device_vec(st.x_tensor(), like)
     return (x_k, history) if return_history else x_k
 
@@ -419,13 +484,14 @@ def fista(A, b, reg_type: str, alpha1: float, alpha2: float, backtracking: bool 
 # ---------------------------------------------------------------------
 def fista_delta(A, b, reg_type: str, alpha1: float, alpha2: float, delta: float, backtracking: bool = False,
                 eta: float = 0.5, t_init_factor: float = 1.0, max_iter: int = 500, tol: float = 0.0,
-                tol_ratio: float = 0.0, return_history: bool = False, *, L=None, dtype=None, check_every=None):
+                tol_ratio: float = 0.0, return_history: bool = False, *, L=None, dtype=None, check_every=None,
+                comm=None, group=None):
     reset_metrics()
     # Course requirement: delta > 2 for convergence guarantee                   ref:268
     assert delta > 2, "In FISTA-Δ, delta must be > 2 for convergence (course requirement)"
-    prob = _core.as_problem(A, b, dtype)
+    prob, reducer = _sharded_problem(A, b, dtype, comm, group)
     like = prob.like
-    L_val = estimate_lipschitz(prob) if L is None else float(L)               # ref:273
+    L_val = estimate_lipschitz(prob, group=group if reducer is not None else None) if L is None else float(L)   # ref:273
     if alpha2 > 0:
         L_val += alpha2
     tau = t_init_factor / L_val
@@ -433,7 +499,7 @@ def fista_delta(A, b, reg_type: str, alpha1: float, alpha2: float, delta: float,
     obj = _objective_by_reg(reg_type, alpha1, alpha2) if return_history else None
     st = _drive(prob, like, mode=_lib.MODE_DELTA, prox_kind=_lib.PROX_L1, alpha1=alpha1, alpha2=alpha2, tau=tau,
                 delta=delta, backtracking=backtracking, eta=eta, max_iter=max_iter, tol=tol, tol_ratio=tol_ratio,
-                grad_tol_check=False, history=history, history_obj=obj, check_every=check_every)
+                grad_tol_check=False, history=history, history_obj=obj, check_every=check_every, reducer=reducer)
     x_k = _core.from_device_vec(st.x_tensor(), like)
     return (x_k, history) if return_history else x_k
 

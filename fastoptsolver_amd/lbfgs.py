@@ -28,9 +28,14 @@ _EPS = float(np.finfo(np.float64).eps)
 class _HipOps:
     """The device primitives of one fit: fp64 K2 pass, fp64 two-loop K4, fp64 n-vector kernels.  No CPU fallback."""
 
-    def __init__(self, A, b):
+    def __init__(self, A, b, comm=None):
         self.lib = _lib.load()
-        self.prob = _core.as_problem(A, b)
+        if comm is not None:                     # row shard: same device length on every rank, sums under the C ABI
+            self.prob = A if isinstance(A, _core.Problem) else _core.Problem(A, b, pad=True)
+            if getattr(self.prob, "comm", None) is not comm:
+                self.prob.set_comm(comm)
+        else:
+            self.prob = _core.as_problem(A, b)
         self.n, self.dev = self.prob.n_dev, self.prob.device   # device length (zero-padded columns stay exactly zero)
         self._stats = torch.zeros(8, dtype=torch.float64, device=self.dev)
         self.rr = self._stats[5:6]
@@ -112,14 +117,16 @@ class LBFGSSolver:
         self.history_ = []
 
     # ------------------------------------------------------------------------------------------------------
-    def fit(self, A, b, *, group=None, ops=None):
-        """``group``: a torch.distributed process group -> A, b are THIS RANK's rows of a row-sharded problem; every
-        ``fg`` all-reduces [partial gradient ; partial ||r||^2] once and all ranks take identical
-        decisions on identical numbers, so x stays replicated bit for bit.  ``ops``: the vector/pass primitives
-        (default: the HIP kernels; the gloo CPU test injects a stand-in)."""
+    def fit(self, A, b, *, group=None, comm=None, ops=None):
+        """``group`` / ``comm``: A, b are THIS RANK's rows of a row-sharded problem; every ``fg`` all-reduces
+        [partial gradient ; partial ||r||^2] (n + 1 doubles) once and all ranks take identical decisions on
+        identical numbers, so x stays replicated bit for bit.  ``comm`` (a `distributed.Comm`): the all-reduce runs
+        under the C ABI on the kernels' stream (inside fos_gemv_pair_dd); ``group`` (a torch.distributed group, any
+        backend): it runs here, between the kernels.  ``ops``: the vector/pass primitives (default: the HIP kernels;
+        the gloo CPU test injects a stand-in)."""
         reset_metrics()
-        ops = ops if ops is not None else _HipOps(A, b)
-        sharded = group is not None and dist.get_world_size(group) > 1
+        ops = ops if ops is not None else _HipOps(A, b, comm)
+        sharded = comm is None and group is not None and dist.get_world_size(group) > 1
         a2 = float(self.alpha2) if self.reg_type in ("ridge", "elasticnet") else 0.0   # lbfgs.py:49-51
         # alpha2*x enters the summed gradient exactly once: rank 0 adds it inside its pass, the others do not
         a2_pass = a2 if (not sharded or dist.get_rank(group) == 0) else 0.0

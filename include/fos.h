@@ -31,7 +31,10 @@ enum { FOS_MODE_FISTA = 0, FOS_MODE_DELTA = 1, FOS_MODE_ISTA = 2 };
 enum { FOS_PROX_L1 = 0, FOS_PROX_ENET = 1 };
 enum { FOS_STOP_NONE = 0, FOS_STOP_STEP = 1, FOS_STOP_RATIO = 2, FOS_STOP_GRAD = 3 };
 
+enum { FOS_PLAN_NO_RESIDENT = 1, FOS_PLAN_NO_TALL = 2, FOS_PLAN_NO_WIDE = 4 };   /* fos_problem_replan */
+
 typedef struct fos_problem fos_problem;   /* A, b, launch plan, workspace            */
+typedef struct fos_comm fos_comm;         /* communicator of a row-sharded problem   */
 typedef struct fos_fista fos_fista;       /* iterate + momentum state of one solve   */
 
 /* Solver parameters: the keyword arguments of fista() iterative_solvers.py:132-147,
@@ -77,11 +80,37 @@ int fos_problem_destroy(fos_problem* p);
  *               LDS-resident loop that fos_fista_run / _run_history / fos_power_iter then use; bit 2: n <= 64, the
  *               single pass is the row-per-thread kernel, which has no alignment requirements), CUs} */
 int fos_problem_plan(const fos_problem* p, int32_t plan[8]);
+/* Re-run the planner with kernel families switched off (FOS_PLAN_* bits): NO_RESIDENT keeps small problems off the
+ * one-launch LDS-resident loop, NO_TALL keeps n <= 64 off the row-per-thread pass, NO_WIDE keeps 16384 < n <= 32768 off
+ * the y-in-LDS pass; each then takes the next family that fits (streaming single pass, two-pass).  For tests and
+ * A/B measurements; call before creating fos_fista handles on the problem.  Synchronises (reallocates workspace). */
+int fos_problem_replan(fos_problem* p, unsigned flags);
 /* Benchmark/tuning override of the fused-kernel geometry; returns FOS_ERR_UNSUPPORTED if not instantiated. */
 int fos_problem_tune(fos_problem* p, int threads, int chunks, int rows, int workgroups);
 /* Use a caller-owned gradient buffer (n + 4 floats, 16-byte aligned) instead of the internal one, e.g. a
  * torch tensor that torch.distributed all-reduces between fos_fista_grad and fos_fista_update. */
 int fos_problem_set_gbuf(fos_problem* p, float* gbuf);
+
+/* ---- row-sharded problems (the reference is single-process) --------------------------------------------
+ * One process per GPU; each rank binds ITS rows of A and b to a fos_problem and attaches a communicator.  From then on
+ * every result of a pass over A that is a sum over rows - fos_gemv_pair* (gradient and ||r||^2), fos_residual_objective
+ * and fos_residual_batch (||A x - b||^2), the Armijo trials, the history residual of fos_fista_grad_dual, the power
+ * iteration - is summed over the ranks on the handle's stream before anything consumes it: ONE all-reduce of n + 1
+ * floats per FISTA iteration (n + 1 doubles per L-BFGS fg), alpha2*y added after the reduction.  x_k, x_{k-1} and the
+ * momentum scalars are replicated; every rank computes the identical update from identical numbers.  fos_fista_run
+ * stays enqueue-only.  All ranks must issue the same calls in the same order.
+ * Transport: RCCL over xGMI, resolved with dlopen at first use (fos_comm_transport() says which library).
+ *   fos_comm_unique_id   rank 0 creates the 128-byte id; the caller broadcasts it out of band (e.g. torch.distributed)
+ *   fos_comm_create      collective over all ranks (ncclCommInitRank) on the CURRENT device
+ *   fos_problem_set_comm attach (NULL detaches); the problem then never uses the one-workgroup resident loop. */
+int fos_comm_unique_id(char id[128]);
+int fos_comm_create(fos_comm** out, const char id[128], int nranks, int rank);
+int fos_comm_destroy(fos_comm* c);
+int fos_comm_info(const fos_comm* c, int* nranks, int* rank);
+const char* fos_comm_transport(void);
+/* In-place sum over the ranks of `count` floats (is_f64 = 0) or doubles (1) on `stream`; enqueues only. */
+int fos_comm_allreduce(fos_comm* c, void* buf, int64_t count, int is_f64, void* stream);
+int fos_problem_set_comm(fos_problem* p, fos_comm* c);
 
 /* Kernel timing for roofline reports: while enabled (enable = N > 0), every N-th launch of the single-pass kernel
  * (or of the two fallback kernels, or of the batched MFMA pass) is bracketed by a pair of hipEvents recorded on the

@@ -655,15 +655,15 @@ def test_ista_with_arbitrary_torch_closures(fos):
 
 @pytest.mark.parametrize("m,n,nv", [(64, 16, 16), (1000, 512, 5), (777, 132, 3), (4099, 8192, 16), (130, 16384, 9), (1, 4, 1),
                                     (32845, 260, 7)])          # the last one is tall enough for the 128-row tile
-def test_residual_batch_mfma_vs_oracle(fos, m, n, nv, monkeypatch):
+def test_residual_batch_mfma_vs_oracle(fos, m, n, nv):
     """The batched (matrix-core) residual kernel: ||A X_j - b||^2 for up to 16 vectors in one pass."""
-    monkeypatch.setenv("FOS_NO_TALL", "1")      # n <= 64 would plan the row-per-thread pass, which has no MFMA batch
     rng = np.random.default_rng(m + n + nv)
     A = rng.standard_normal((m, n)).astype(np.float32)
     b = rng.standard_normal(m).astype(np.float32)
     X = (rng.standard_normal((n, nv)) * np.logspace(0, -6, nv)).astype(np.float32)   # candidates shrink like t*eta^j
     prob = fos.prepare(A, b)
-    assert prob.plan()["path"] == 0
+    prob.replan(no_tall=True)                   # n <= 64 would plan the row-per-thread pass, which has no MFMA batch
+    assert prob.plan()["path"] == 0 and prob.plan()["tall"] == 0
     for use_b in (True, False):
         got = prob.residual_batch(X, use_b=use_b)
         R = A.astype(np.float64) @ X.astype(np.float64) - (b.astype(np.float64)[:, None] if use_b else 0.0)
@@ -673,16 +673,16 @@ def test_residual_batch_mfma_vs_oracle(fos, m, n, nv, monkeypatch):
 
 @pytest.mark.parametrize("m,n,nv", [(64, 16, 16), (1000, 512, 5), (777, 136, 3), (4099, 8192, 16), (130, 16384, 9), (1, 8, 1),
                                     (32845, 264, 7)])          # the last one is tall enough for the 128-row tile
-def test_residual_batch_mfma_bf16_vs_oracle(fos, m, n, nv, monkeypatch):
+def test_residual_batch_mfma_bf16_vs_oracle(fos, m, n, nv):
     """bf16 A on v_mfma_f32_16x16x32_bf16: the candidates are split into three bf16 terms (24 mantissa bits), so the
     result keeps the fp32 tolerance against the float64 product with the bf16-ROUNDED A."""
-    monkeypatch.setenv("FOS_NO_TALL", "1")
     rng = np.random.default_rng(m + n + nv)
     A16 = torch.as_tensor(rng.standard_normal((m, n)).astype(np.float32)).to(torch.bfloat16)
     Aq = A16.to(torch.float64).numpy()
     b = rng.standard_normal(m).astype(np.float32)
     X = (rng.standard_normal((n, nv)) * np.logspace(0, -6, nv)).astype(np.float32)
     prob = fos.prepare(A16.cuda(), b)
+    prob.replan(no_tall=True)
     assert prob.plan()["path"] == 0 and prob.dtype == "bf16"
     for use_b in (True, False):
         got = prob.residual_batch(X, use_b=use_b)
@@ -943,15 +943,16 @@ def test_resident_run_reports_stops_steps_and_counts(fos):
     assert big.plan()["resident"] == 0 and _core.Fista(big).run_resident(1) is None
 
 
-def test_resident_and_multi_launch_paths_agree(fos, monkeypatch):
-    """FOS_NO_RESIDENT=1 keeps small problems on the streaming kernels: same iterates either way."""
+def test_resident_and_multi_launch_paths_agree(fos):
+    """replan(no_resident=True) keeps small problems on the multi-launch kernels: same iterates either way."""
     A, b, fx = _data.problem("tiny")
     lam = float(np.max(np.abs(A.T @ b)))
     L = float(fx["tiny/L"])
     kw = dict(max_iter=60, L=L, backtracking=True, t_init_factor=2.0, return_history=True)
     x1, h1 = fos.fista(A, b, "lasso", 0.05 * lam, 0.0, **kw)
-    monkeypatch.setenv("FOS_NO_RESIDENT", "1")
     prob = fos.prepare(A, b)
+    assert prob.plan()["resident"] == 1
+    prob.replan(no_resident=True)
     assert prob.plan()["resident"] == 0
     x2, h2 = fos.fista(prob, None, "lasso", 0.05 * lam, 0.0, **kw)
     assert _data.rel(x1, x2) < 1e-6 and np.allclose(h1["obj"], h2["obj"], rtol=1e-6)

@@ -90,3 +90,121 @@ def test_two_ranks_share_the_gpu(tmp_path):
     ref = orc.LBFGSSolver("ridge", 0.0, a2).fit(A, b)
     assert _data.rel(r0["xl"], ref.x_) < TOL and int(r0["nfev"]) == ref.nfev_
     assert float(r0["fl"]) == pytest.approx(ref.final_obj_, rel=1e-6)
+
+
+# --------------------------------------------------------------------------------------------------
+# RCCL under the C ABI: a one-rank communicator forces every exchange through ncclAllReduce on the kernels' stream
+# --------------------------------------------------------------------------------------------------
+def test_rccl_communicator_on_the_kernels_stream_matches_oracle():
+    """Comm.solo() = ncclCommInitRank with one rank: the sharded code path end to end on one GPU - fos_fista_run
+    enqueues K2 -> slab reduce -> ncclAllReduce(n + 1 floats) -> prox/momentum per iteration with no host step; the
+    Armijo trials, the history residual, the power iteration and the L-BFGS fg all-reduce their sums the same way.
+    Everything must equal the unsharded oracle (a sum over one rank is the identity)."""
+    import fastoptsolver_amd as fos
+    from fastoptsolver_amd import distributed as fd
+    comm = fd.Comm.solo()
+    assert comm.transport().startswith("rccl"), comm.transport()
+    t = torch.arange(5, dtype=torch.float64, device="cuda")
+    assert torch.equal(comm.allreduce(t.clone()), t)
+    A, b, _ = _data.synth(*SHAPE)
+    a1, a2 = _weights(A, b)
+    np.random.seed(0)
+    v0 = np.random.randn(A.shape[1])
+    L_ref = orc.estimate_lipschitz(A, v0=v0)
+    A32, b32 = A.astype(np.float32), b.astype(np.float32)
+    # (1) enqueue-only sharded run through the engine
+    eng = fd.HipShardEngine(A32, b32, comm=comm)
+    assert eng.prob.plan()["resident"] == 0
+    eng.reset(tau=1.0 / (L_ref + a2), alpha1=a1, alpha2=a2)
+    fd.ShardedFista(eng).run(40)
+    x_ref = orc.fista(A, b, "elasticnet", a1, a2, max_iter=40, L=L_ref)
+    assert _data.rel(eng.x().cpu().numpy(), x_ref) < TOL and int(eng.status().k) == 40
+    # (2) the reference's front-end with every flag, on a shard problem with the communicator attached
+    np.random.seed(0)
+    assert fos.estimate_lipschitz(eng.prob) == pytest.approx(L_ref, rel=TOL)
+    for kw in (dict(backtracking=True, t_init_factor=2.0), dict(adaptive_restart=True), dict(tol=1e-3), dict(tol_ratio=0.9)):
+        x, h = fos.fista(A32, b32, "elasticnet", a1, a2, max_iter=60, L=L_ref, return_history=True, comm=comm, **kw)
+        x_ref, h_ref = orc.fista(A, b, "elasticnet", a1, a2, max_iter=60, L=L_ref, return_history=True, **kw)
+        assert len(h["obj"]) == len(h_ref["obj"]), kw
+        assert _data.rel(x, x_ref) < TOL and np.allclose(h["obj"], h_ref["obj"], rtol=TOL), kw
+    x = fos.fista_delta(A32, b32, "lasso", a1, 0.0, 3.0, max_iter=50, L=L_ref, comm=comm)
+    assert _data.rel(x, orc.fista_delta(A, b, "lasso", a1, 0.0, 3.0, max_iter=50, L=L_ref)) < TOL
+    # (3) L-BFGS: fg's n + 1 doubles through the communicator
+    s = fos.LBFGSSolver("ridge", 0.0, a2).fit(A32, b32, comm=comm)
+    ref = orc.LBFGSSolver("ridge", 0.0, a2).fit(A32.astype(np.float64), b32.astype(np.float64))
+    assert (s.nit_, s.nfev_) == (ref.nit_, ref.nfev_) and _data.rel(s.x_, ref.x_) < TOL
+    # (4) bf16 shard (config 5 in miniature) through the same path
+    A16 = torch.as_tensor(A32).to(torch.bfloat16).cuda()
+    e16 = fd.HipShardEngine(A16, b32, comm=comm)
+    e16.reset(tau=1.0 / (L_ref + 10.0), alpha1=a1, alpha2=10.0)
+    e16.run(30)
+    x_ref = orc.fista(A16.to(torch.float64).cpu().numpy(), b32.astype(np.float64), "elasticnet", a1, 10.0, max_iter=30,
+                      L=L_ref)
+    assert _data.rel(e16.x().cpu().numpy(), x_ref) < TOL
+
+
+# --------------------------------------------------------------------------------------------------
+# two ranks, split form over gloo: every flag of the reference's loop on a row-sharded problem, and config 5 in miniature
+# --------------------------------------------------------------------------------------------------
+CASES = [dict(), dict(backtracking=True, t_init_factor=2.0), dict(adaptive_restart=True), dict(tol=1e-3),
+         dict(tol_ratio=0.9)]
+
+
+def _flags_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import fastoptsolver_amd as fos
+    from fastoptsolver_amd import distributed as fd
+    A, b, _ = _data.synth(*SHAPE)
+    a1, a2 = _weights(A, b)
+    lo, hi = fd.shard_rows(A.shape[0], world, rank)
+    As, bs = A[lo:hi].astype(np.float32), b[lo:hi].astype(np.float32)
+    out = {}
+    np.random.seed(0)
+    out["L"] = fos.estimate_lipschitz(fos.prepare(As, None), group=dist.group.WORLD)
+    L = out["L"]
+    for i, kw in enumerate(CASES):
+        x, h = fos.fista(As, bs, "elasticnet", a1, a2, max_iter=60, L=L, return_history=True, group=dist.group.WORLD, **kw)
+        out[f"x{i}"], out[f"obj{i}"] = np.asarray(x), np.asarray(h["obj"])
+        out[f"ls{i}"] = np.asarray(fos.get_metrics()["ls_iters_total"])
+    x, h = fos.fista_delta(As, bs, "lasso", a1, 0.0, 3.0, max_iter=40, L=L, return_history=True, group=dist.group.WORLD)
+    out["xd"], out["objd"] = np.asarray(x), np.asarray(h["obj"])
+    # config 5 in miniature: bf16 storage, l1 + l2, row-sharded
+    A16 = torch.as_tensor(As).to(torch.bfloat16).cuda()
+    x5 = fos.fista(A16, bs, "elasticnet", a1, 10.0, max_iter=40, L=L, group=dist.group.WORLD)
+    out["x5"] = x5.float().cpu().numpy() if torch.is_tensor(x5) else np.asarray(x5)
+    eng = fd.HipShardEngine(A16, bs, group=dist.group.WORLD)
+    eng.reset(tau=1.0 / (L + 10.0), alpha1=a1, alpha2=10.0)
+    fd.ShardedFista(eng, dist.group.WORLD).run(40)
+    out["x5e"] = eng.x().cpu().numpy()
+    np.savez(os.path.join(out_dir, f"f{rank}.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_every_flag_and_config5_in_miniature(tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_flags_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "f0.npz"), np.load(tmp_path / "f1.npz")
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), f"replicas drifted apart: {k}"
+    A, b, _ = _data.synth(*SHAPE)
+    a1, a2 = _weights(A, b)
+    np.random.seed(0)
+    L_ref = orc.estimate_lipschitz(A, v0=np.random.randn(A.shape[1]))
+    L = float(r0["L"])
+    assert L == pytest.approx(L_ref, rel=TOL)
+    for i, kw in enumerate(CASES):
+        x_ref, h_ref = orc.fista(A, b, "elasticnet", a1, a2, max_iter=60, L=L, return_history=True, **kw)
+        assert len(r0[f"obj{i}"]) == len(h_ref["obj"]), kw              # same stopping iteration as the unsharded run
+        assert _data.rel(r0[f"x{i}"], x_ref) < TOL and np.allclose(r0[f"obj{i}"], h_ref["obj"], rtol=TOL), kw
+    x_ref, h_ref = orc.fista_delta(A, b, "lasso", a1, 0.0, 3.0, max_iter=40, L=L, return_history=True)
+    assert _data.rel(r0["xd"], x_ref) < TOL and np.allclose(r0["objd"], h_ref["obj"], rtol=TOL)
+    Aq = torch.as_tensor(A.astype(np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
+    x5_ref = orc.fista(Aq, b.astype(np.float32).astype(np.float64), "elasticnet", a1, 10.0, max_iter=40, L=L)
+    assert _data.rel(r0["x5"], x5_ref) < TOL and _data.rel(r0["x5e"], x5_ref) < TOL
