@@ -139,16 +139,34 @@ def run_workload(name, args, rank, world, device, steps, warmup, want_cpu, dist)
     torch.cuda.synchronize()
     log(f"[rank {rank}] {name}: rows [{lo},{hi}) x {n} {cfg['dtype']} generated in {time.perf_counter() - t0:.1f}s")
 
-    eng = fd.HipShardEngine(A, b)
+    # N > 1 over RCCL: the communicator lives under the C ABI and every row-sum of this rank's shard is all-reduced on
+    # the kernels' own stream - K2 -> slab reduce -> ncclAllReduce(n + 1 floats) -> prox + momentum, `k` iterations
+    # enqueued without a host step (the gloo rehearsal keeps the split form driven from Python).
+    comm = None
+    if world > 1 and args.backend == "nccl":
+        try:
+            comm = fd.Comm(dist.group.WORLD)
+            ok = 1.0
+        except Exception as exc:                 # e.g. no loadable RCCL for dlopen: fall back to the split form, loudly
+            log(f"[rank {rank}] fos_comm unavailable ({exc}); falling back to torch.distributed all-reduce")
+            ok = 0.0
+        flag = torch.tensor([ok], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # all ranks take the same path
+        if float(flag.item()) < 1.0:
+            comm = None
+    args.comm_mode = "c-abi" if comm is not None else ("torch" if world > 1 else "none")
+    eng = fd.HipShardEngine(A, b, comm=comm, group=dist.group.WORLD if world > 1 else None)
     matvec_prob = fos.prepare(A, None)                       # same A, b = 0: power iteration / A^T b
+    if comm is not None:
+        matvec_prob.set_comm(comm)
     if args.geometry:
         th, ch, rw, wg = (int(v) for v in args.geometry.split("x"))
         eng.prob.tune(th, ch, rw, wg)
         matvec_prob.tune(th, ch, rw, wg)
 
     # alpha1 = frac * ||A^T b||_inf  (A^T b = -grad at y = 0)
-    atb = eng.prob.gemv_pair(torch.zeros(n, device=device), 0.0)
-    if world > 1:
+    atb = eng.prob.gemv_pair(torch.zeros(n, device=device), 0.0)          # summed over the ranks when comm is attached
+    if world > 1 and comm is None:
         dist.all_reduce(atb)
     a1 = cfg["a1_frac"] * vec_stats(None, atb, None)[3]
     a2 = cfg["a2"]
@@ -157,7 +175,10 @@ def run_workload(name, args, rank, world, device, steps, warmup, want_cpu, dist)
     np.random.seed(0)
     v0 = torch.from_numpy(np.random.randn(n).astype(np.float32)).to(device)
     t0 = time.perf_counter()
-    L = fd.sharded_lipschitz(lambda v: matvec_prob.gemv_pair(v, 0.0), n, v0)
+    if comm is not None:
+        L = matvec_prob.power_iter(v0)[0]                    # fos_power_iter: w all-reduced on the stream
+    else:
+        L = fd.sharded_lipschitz(lambda v: matvec_prob.gemv_pair(v, 0.0), n, v0)
     torch.cuda.synchronize()
     lip_s = time.perf_counter() - t0
     tau = 1.0 / (L + (a2 if a2 > 0 else 0.0))
@@ -168,7 +189,7 @@ def run_workload(name, args, rank, world, device, steps, warmup, want_cpu, dist)
         if world == 1:
             eng.st.run(k)          # fused device-driven path: K2 -> (slab reduce + prox + momentum) -> finalize
         else:
-            solver.run(k)          # K2 -> slab reduce -> RCCL all-reduce(n+1) -> prox + momentum -> finalize
+            solver.run(k)          # comm: enqueue-only under the C ABI; gloo rehearsal: split form from Python
 
     def fence():
         torch.cuda.synchronize()
@@ -177,16 +198,23 @@ def run_workload(name, args, rank, world, device, steps, warmup, want_cpu, dist)
         torch.cuda.synchronize()
 
     do_steps(warmup)
-    x_check, k_check = None, max(warmup, 3)
+    x_check, k_check, a1_chk = None, max(warmup, 3), a1
     if want_cpu and rank == 0 and world == 1:
         # Parity sample, outside the timed region: the same plan family on the rows the CPU baseline copies (all of
         # cfg2; the first 65536 rows of cfg4 / cfg5), same L / alpha1 / alpha2, k_check iterations from x = 0.
+        # alpha1 keeps its meaning on the sample: the same fraction of the SAMPLE's ||A^T b||_inf (the full problem's
+        # alpha1 would threshold every coordinate of a 16x smaller problem to zero and make the check vacuous).
         rows = min(m, SAMPLE_ROWS)
+        a1_chk = a1
         sub = eng if rows == m and warmup == k_check else fd.HipShardEngine(A[:rows], b[:rows])
         if sub is not eng:
-            sub.reset(tau=tau, alpha1=a1, alpha2=a2)
+            if rows != m:
+                atb_s = sub.prob.gemv_pair(torch.zeros(n, device=device), 0.0)
+                a1_chk = cfg["a1_frac"] * vec_stats(None, atb_s, None)[3]
+            sub.reset(tau=tau, alpha1=a1_chk, alpha2=a2)
             sub.st.run(k_check)
         x_check = sub.x().cpu().numpy()
+        assert np.linalg.norm(x_check) > 0.0, "parity sample did not move: vacuous check"
         del sub
     # HIP events around the launches of the dominant kernel: all of them for short runs, every 8th otherwise (the
     # markers cost ~1 % when they bracket every launch of a long run)
@@ -218,11 +246,11 @@ def run_workload(name, args, rank, world, device, steps, warmup, want_cpu, dist)
         final_step_norm=st.this_step)
     cpu, parity = None, None
     if want_cpu and rank == 0 and world == 1:
-        cpu, parity = cpu_baseline(cfg, A, b, a1, a2, L, x_check, k_check)
+        cpu, parity = cpu_baseline(cfg, A, b, a1_chk, a2, L, x_check, k_check)
         assert parity is not None and parity < 1e-5, f"GPU iterate {k_check} differs from the oracle by {parity}: invalid run"
     res["cpu_baseline"], res["parity_rel_err"], res["parity_k"] = cpu, parity, k_check
     res["parity_rows"] = min(m, SAMPLE_ROWS)
-    del solver, eng, matvec_prob, A, b
+    del solver, eng, matvec_prob, A, b, comm
     torch.cuda.empty_cache()
     return res
 
@@ -279,6 +307,7 @@ def main():
     # REHEARSAL ONLY (FOS_BENCH_BACKEND=gloo): lets N ranks share one GPU on a 1-GPU box to exercise the N>1 code
     # path (sharding, barriers, all-reduce, JSON); its numbers are meaningless and are labelled as such.
     backend = os.environ.get("FOS_BENCH_BACKEND", "nccl")
+    args.backend = backend
     dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -336,7 +365,9 @@ def main():
                             f"rows sharded over {world} GPU(s), alpha1={res['alpha1']:.4g}, alpha2={res['alpha2']}",
                 "m": cfg["m"], "n": cfg["n"], "rows_per_gpu": res["rows_per_gpu"],
                 "sharding": f"rows/{world}" if world > 1 else "none",
-                "collective": "RCCL all-reduce(SUM) of n+1 fp32 per iteration" if world > 1 else "none",
+                "collective": ("ncclAllReduce(SUM) of n+1 fp32 per iteration, enqueued by libfos_hip.so on the kernels' stream"
+                               if getattr(args, "comm_mode", "") == "c-abi" else
+                               ("torch.distributed all-reduce of n+1 fp32 per iteration (split form)" if world > 1 else "none")),
                 "kernel_plan": res["plan"],
                 "iterate_state": "fp64 on device; y rounded once to fp32 for the single pass over A",
                 "backend": backend if world > 1 else None,

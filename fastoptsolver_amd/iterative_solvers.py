@@ -157,7 +157,7 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
     st.reset(tau, alpha1, alpha2, mode=mode, prox_kind=prox_kind, delta=delta, adaptive_restart=adaptive_restart,
              restart_threshold=restart_threshold, tol_step=tol if tol > 0.0 else 0.0,
              tol_ratio=tol_ratio if tol_ratio > 0.0 else 0.0, x0=x0_dev)
-    gtimer = _EventTimer(grad_call_times)
+    gtimer = getattr(st, "make_timer", _EventTimer)(grad_call_times)     # stand-in states bring a host timer
     # reducer: split-form sharding - the all-reduce sits between the gradient and the update, so the host drives
     host_driven = (backtracking or history is not None or log is not None or (grad_tol_check and tol > 0.0)
                    or reducer is not None)

@@ -207,3 +207,196 @@ def test_two_rank_gloo_sharded_lbfgs(tmp_path):
     assert abs(int(r0["nit"]) - len(ref.history_)) <= 1
     k = min(len(r0["hist"]), len(ref.history_))
     assert np.allclose(r0["hist"][:k], ref.history_[:k], rtol=1e-9)    # callback objective incl. alpha1*||x||_1
+
+
+# --------------------------------------------------------------------------------------------------
+# split-form sharding of the FULL loop (backtracking, history, restart, stops): the product's driver
+# (iterative_solvers._drive + _GroupReducer) with a NumPy stand-in for the device state machine
+# --------------------------------------------------------------------------------------------------
+class _Status:
+    pass
+
+
+class _HostTimer(_NoTimer):
+    def __init__(self, sink):
+        self.sink, self.pending = sink, []
+
+    def stop(self, ev, count=1):
+        self.sink.extend([0.0] * count)
+
+
+class _FakeProblem:
+    """What _drive / _GroupReducer touch on a Problem: gbuf, n, n_dev, device, residual_objective."""
+
+    def __init__(self, A, b):
+        self.A, self.b = A, b
+        self.n = self.n_dev = A.shape[1]
+        self.device = torch.device("cpu")
+        self.gbuf = torch.zeros(self.n + 4, dtype=torch.float64)
+
+    def residual_objective(self, x):
+        x = x.numpy()
+        r = self.A @ x - self.b
+        return float(r @ r), float(x @ x), float(np.abs(x).sum())
+
+
+class OracleFistaState:
+    """Interface of fastoptsolver_amd._core.Fista (reset / grad / trial / update / status / x_tensor), arithmetic of
+    reduce_update.hpp restated in NumPy float64 on THIS RANK's rows; test infrastructure only."""
+    make_timer = _HostTimer
+
+    def __init__(self, prob):
+        self.p = prob
+
+    def reset(self, tau, alpha1, alpha2, mode=0, prox_kind=0, delta=0.0, adaptive_restart=False, restart_threshold=1.0,
+              tol_step=0.0, tol_ratio=0.0, x0=None):
+        n = self.p.n
+        self.tau, self.a1, self.a2, self.mode, self.delta = tau, alpha1, alpha2, mode, delta
+        self.restart, self.thr, self.tol_step, self.tol_ratio = adaptive_restart, restart_threshold, tol_step, tol_ratio
+        self.xc, self.xp = np.zeros(n), np.zeros(n)
+        self.t, self.beta, self.k, self.stopped = 1.0, 0.0, 0, 0
+        self.this_step, self.rr_x, self.x1, self.x2 = 0.0, 0.0, 0.0, 0.0
+
+    def _y(self):
+        return self.xc + self.beta * (self.xc - self.xp)
+
+    def set_tau(self, tau):
+        self.tau = tau
+
+    def grad(self, dual=False):
+        if self.stopped:
+            return
+        r = self.p.A @ self._y() - self.p.b
+        self.p.gbuf[: self.p.n] = torch.from_numpy(self.p.A.T @ r)
+        self.p.gbuf[self.p.n] = float(r @ r)
+        if dual:
+            rx = self.p.A @ self.xc - self.p.b
+            self.rr_x = float(rx @ rx)
+
+    def _trial_point(self, t):
+        y = self._y()
+        gf = self.p.gbuf[: self.p.n].numpy() + (self.a2 * y if self.a2 > 0 else 0.0)
+        v = y - t * gf
+        return y, gf, (orc.prox_l1(v, t * self.a1) if self.a1 > 0 else v)
+
+    def trial(self, t, with_residual=True):
+        y, gf, xt = self._trial_point(t)
+        d = xt - y
+        Ad = self.p.A @ d
+        return dict(gd=float(gf @ d), dd=float(d @ d), nnz=float(np.count_nonzero(d)), gnorm2=float(gf @ gf),
+                    y2=float(y @ y), q=float(Ad @ Ad) if with_residual else 0.0, rr_y=float(self.p.gbuf[self.p.n]))
+
+    def trial_batch(self, t, eta, nv):
+        return None
+
+    def run_resident(self, *a, **k):
+        return None
+
+    def run_history(self, iters):
+        return None
+
+    def update(self):
+        if self.stopped:
+            return
+        _, _, xn = self._trial_point(self.tau)
+        step = float(np.linalg.norm(xn - self.xc))
+        prev = self.this_step
+        ratio = step / prev if prev > 0 else float("inf")
+        if self.mode == 0:
+            if self.restart and ratio > self.thr:
+                t_new, beta = 1.0, 0.0
+            else:
+                t_new = 0.5 * (1.0 + np.sqrt(1.0 + 4.0 * self.t ** 2))
+                beta = (self.t - 1.0) / t_new
+            self.t = t_new
+        elif self.mode == 1:
+            kk = float(self.k + 1)
+            beta = kk / (kk + 1.0 + self.delta)
+        else:
+            beta = 0.0
+        self.beta, self.this_step = beta, step
+        self.xp, self.xc = self.xc, xn
+        self.x1, self.x2 = float(np.abs(xn).sum()), float(xn @ xn)
+        self.k += 1
+        if self.tol_step > 0 and step < self.tol_step:
+            self.stopped = 1
+        elif self.tol_ratio > 0 and ratio < self.tol_ratio:
+            self.stopped = 2
+
+    def status(self):
+        s = _Status()
+        s.stopped, s.k, s.rr_x, s.xnorm1, s.xnorm2, s.this_step = self.stopped, self.k, self.rr_x, self.x1, self.x2, self.this_step
+        return s
+
+    def x_tensor(self):
+        return torch.from_numpy(self.xc.copy())
+
+
+FLAG_CASES = [dict(), dict(backtracking=True, t_init=2.0), dict(adaptive_restart=True), dict(tol=2e-3), dict(tol_ratio=0.9),
+              dict(mode=1, delta=3.0, backtracking=True, t_init=1.0)]
+
+
+def _flags_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fastoptsolver_amd import iterative_solvers as its
+    A, b, _ = _data.synth(1001, 48, 9)
+    lam = float(np.max(np.abs(A.T @ b)))
+    a1, a2 = 0.05 * lam, 0.5
+    L = float(np.linalg.norm(A, 2) ** 2)
+    lo, hi = fd.shard_rows(A.shape[0], world, rank)
+    out = {}
+    for i, c in enumerate(FLAG_CASES):
+        prob = _FakeProblem(A[lo:hi], b[lo:hi])
+        history = {"x": [], "obj": []}
+        mode = c.get("mode", 0)
+        st = its._drive(prob, np.zeros(1), mode=mode, prox_kind=0, alpha1=a1, alpha2=a2, tau=c.get("t_init", 1.0) / (L + a2),
+                        delta=c.get("delta", 0.0), backtracking=c.get("backtracking", False), max_iter=50,
+                        tol=c.get("tol", 0.0), tol_ratio=c.get("tol_ratio", 0.0),
+                        adaptive_restart=c.get("adaptive_restart", False), grad_tol_check=(mode == 0),
+                        history=history, history_obj=its._objective_by_alpha(a1, a2),
+                        reducer=its._GroupReducer(prob, dist.group.WORLD), state=OracleFistaState(prob))
+        out[f"x{i}"], out[f"obj{i}"] = st.x_tensor().numpy(), np.asarray(history["obj"])
+        out[f"ls{i}"] = np.asarray(its.get_metrics()["ls_iters_total"])
+        its.reset_metrics()
+    np.savez(os.path.join(out_dir, f"flags{rank}.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_every_flag_of_the_loop(tmp_path):
+    """Backtracking (sum of ||A_p dlt||^2), history (sum of ||A_p x - b_p||^2, closing residual pass), adaptive
+    restart and the three stopping rules on a row-sharded problem equal the unsharded oracle: same iterates, same
+    objective history, same stopping iteration, same number of Armijo shrinks."""
+    world = 2
+    mp.spawn(_flags_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "flags0.npz"), np.load(tmp_path / "flags1.npz")
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), f"replicas drifted apart: {k}"
+    A, b, _ = _data.synth(1001, 48, 9)
+    lam = float(np.max(np.abs(A.T @ b)))
+    a1, a2 = 0.05 * lam, 0.5
+    L = float(np.linalg.norm(A, 2) ** 2)
+    for i, c in enumerate(FLAG_CASES):
+        kw = dict(backtracking=c.get("backtracking", False), t_init_factor=c.get("t_init", 1.0), max_iter=50,
+                  tol=c.get("tol", 0.0), tol_ratio=c.get("tol_ratio", 0.0), return_history=True, L=L)
+        if c.get("mode", 0) == 1:
+            ref = orc.fista_delta(A, b, "elasticnet", a1, a2, c["delta"], **kw)
+        else:
+            ref = orc.fista(A, b, "elasticnet", a1, a2, adaptive_restart=c.get("adaptive_restart", False), **kw)
+        x_ref, h_ref = ref
+        assert len(r0[f"obj{i}"]) == len(h_ref["obj"]), c
+        assert _data.rel(r0[f"x{i}"], x_ref) < 1e-9 and np.allclose(r0[f"obj{i}"], h_ref["obj"], rtol=1e-9), c
+        if c.get("backtracking"):
+            assert int(r0[f"ls{i}"]) == orc_ls_total(A, b, a1, a2, c, L), c
+
+
+def orc_ls_total(A, b, a1, a2, c, L):
+    kw = dict(backtracking=True, t_init_factor=c.get("t_init", 1.0), max_iter=50, L=L, return_metrics=True)
+    if c.get("mode", 0) == 1:
+        _, met = orc.fista_delta(A, b, "elasticnet", a1, a2, c["delta"], **kw)
+    else:
+        _, met = orc.fista(A, b, "elasticnet", a1, a2, **kw)
+    return met["ls_iters_total"]
