@@ -116,6 +116,7 @@ class Problem:
                                               _lib.FOS_BF16 if want_bf16 else _lib.FOS_F32, ptr(self.b), stream_ptr()),
                        "fos_problem_create")
             self.h = h
+            self._stream = torch.cuda.current_stream(self.device).cuda_stream
             _lib.check(lib.fos_problem_set_gbuf(self.h, ptr(self.gbuf)), "fos_problem_set_gbuf")
         self.lib = lib
 
@@ -127,6 +128,17 @@ class Problem:
             except Exception:
                 pass
             self.h = None
+
+    def ctx(self):
+        """Device guard for a call into the library; the handle follows torch's CURRENT stream (fos_problem_set_stream
+        orders the new stream behind work still enqueued on the old one), so temporaries allocated by the caching
+        allocator and the kernels that read them always share a stream."""
+        cur = torch.cuda.current_stream(self.device).cuda_stream
+        if cur != self._stream:
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.fos_problem_set_stream(self.h, C.c_void_p(cur)), "fos_problem_set_stream")
+            self._stream = cur
+        return torch.cuda.device(self.device)
 
     # ---- user-length <-> device-length vectors ------------------------------------------------------------
     def vec_in(self, x, dtype=torch.float32):
@@ -162,7 +174,7 @@ class Problem:
         Call before creating Fista handles on this problem."""
         flags = ((_lib.PLAN_NO_RESIDENT if no_resident else 0) | (_lib.PLAN_NO_TALL if no_tall else 0) |
                  (_lib.PLAN_NO_WIDE if no_wide else 0))
-        with torch.cuda.device(self.device):
+        with self.ctx():
             _lib.check(self.lib.fos_problem_replan(self.h, flags), "fos_problem_replan")
 
     def set_comm(self, comm):
@@ -181,7 +193,7 @@ class Problem:
     def profile_read(self):
         """(device milliseconds, launches) of the A-pass kernel since the last read; synchronises."""
         ms, cnt = C.c_double(), C.c_int64()
-        with torch.cuda.device(self.device):
+        with self.ctx():
             _lib.check(self.lib.fos_problem_profile_read(self.h, C.byref(ms), C.byref(cnt)), "fos_problem_profile_read")
         return ms.value, cnt.value
 
@@ -192,7 +204,7 @@ class Problem:
         if out is None or out.numel() != self.n_dev:
             out = torch.empty(self.n_dev, dtype=torch.float32, device=self.device)
         y = self.vec_in(y)
-        with torch.cuda.device(self.device):
+        with self.ctx():
             _lib.check(self.lib.fos_gemv_pair(self.h, ptr(y), float(alpha2), ptr(out), ptr(rr_out)), "fos_gemv_pair")
         if user_out is not None and user_out is not out:
             user_out.copy_(self.vec_out(out))
@@ -202,7 +214,7 @@ class Problem:
     def residual_objective(self, x):
         """Host tuple (||Ax-b||^2, ||x||^2, ||x||_1); synchronises.  x is rounded to fp32 for the pass over A."""
         x = self.vec_in(x)
-        with torch.cuda.device(self.device):
+        with self.ctx():
             _lib.check(self.lib.fos_residual_objective(self.h, ptr(x), ptr(self.scratch)), "fos_residual_objective")
         v = self.scratch[:3].cpu()
         return float(v[0]), float(v[1]), float(v[2])
@@ -213,7 +225,7 @@ class Problem:
         nv = X.shape[1]
         Xf = torch.zeros(self.n_dev, 16, dtype=torch.float32, device=self.device)
         Xf[: X.shape[0], :nv] = X
-        with torch.cuda.device(self.device):
+        with self.ctx():
             _lib.check(self.lib.fos_residual_batch(self.h, ptr(Xf), nv, int(bool(use_b)), ptr(self.scratch)),
                        "fos_residual_batch")
         return self.scratch[:nv].cpu().tolist()
@@ -222,7 +234,7 @@ class Problem:
         v = self.vec_in(v0).clone()
         L = C.c_double()
         it = C.c_int()
-        with torch.cuda.device(self.device):
+        with self.ctx():
             _lib.check(self.lib.fos_power_iter(self.h, ptr(v), int(n_iter), float(tol), C.byref(L), C.byref(it)),
                        "fos_power_iter")
         return L.value, it.value, self.vec_out(v)
@@ -248,7 +260,7 @@ class Fista:
         self.prob = prob
         self.lib = prob.lib
         h = C.c_void_p()
-        with torch.cuda.device(prob.device):
+        with prob.ctx():
             _lib.check(self.lib.fos_fista_create(prob.h, C.byref(h)), "fos_fista_create")
         self.h = h
         self.prm = _lib.FistaParams()
@@ -263,21 +275,22 @@ class Fista:
             self.h = None
 
     def reset(self, tau, alpha1, alpha2, mode=_lib.MODE_FISTA, prox_kind=_lib.PROX_L1, delta=0.0,
-              adaptive_restart=False, restart_threshold=1.0, tol_step=0.0, tol_ratio=0.0, x0=None):
+              adaptive_restart=False, restart_threshold=1.0, tol_step=0.0, tol_ratio=0.0, tol_grad=0.0, x0=None):
         p = self.prm
         p.tau, p.alpha1, p.alpha2, p.delta = float(tau), float(alpha1), float(alpha2), float(delta)
         p.restart_threshold, p.tol_step, p.tol_ratio = float(restart_threshold), float(tol_step), float(tol_ratio)
+        p.tol_grad = float(tol_grad)
         p.mode, p.prox_kind, p.adaptive_restart, p.reserved = int(mode), int(prox_kind), int(bool(adaptive_restart)), 0
         if x0 is not None:
             x0 = self.prob.vec_in(x0, torch.float64)
-        with torch.cuda.device(self.prob.device):
+        with self.prob.ctx():
             _lib.check(self.lib.fos_fista_reset(self.h, C.byref(p), ptr(x0)), "fos_fista_reset")
 
     def set_tau(self, tau):
         _lib.check(self.lib.fos_fista_set_tau(self.h, float(tau)), "fos_fista_set_tau")
 
     def run(self, iters):
-        with torch.cuda.device(self.prob.device):
+        with self.prob.ctx():
             _lib.check(self.lib.fos_fista_run(self.h, int(iters)), "fos_fista_run")
 
     def run_history(self, iters):
@@ -289,7 +302,7 @@ class Fista:
         hist = torch.empty(iters, 4, dtype=torch.float64, device=dev)
         nbytes = self.lib.fos_fista_history_workspace(self.h, int(iters))
         work = torch.empty(max(1, (nbytes + 7) // 8), dtype=torch.float64, device=dev)
-        with torch.cuda.device(dev):
+        with self.prob.ctx():
             rc = self.lib.fos_fista_run_history(self.h, int(iters), ptr(xh), ptr(hist), ptr(work))
         if rc == -4:
             return None
@@ -311,7 +324,7 @@ class Fista:
         ls = torch.zeros(max(iters, 1), dtype=torch.int32, device=dev)
         taus = torch.zeros(max(iters, 1), dtype=torch.float64, device=dev)
         done, tau = C.c_int32(0), C.c_double(0.0)
-        with torch.cuda.device(dev):
+        with self.prob.ctx():
             rc = self.lib.fos_fista_run_resident(self.h, iters, 1 if backtracking else 0, float(eta), float(armijo_c),
                                                  float(grad_tol), ptr(xh), ptr(hist), ptr(ls), ptr(taus),
                                                  C.byref(done), C.byref(tau))
@@ -327,19 +340,19 @@ class Fista:
 
     def grad(self, dual=False):
         """Gradient pass at y_k; dual=True also leaves ||A x_k - b||^2 in status().rr_x (same pass over A)."""
-        with torch.cuda.device(self.prob.device):
+        with self.prob.ctx():
             if dual:
                 _lib.check(self.lib.fos_fista_grad_dual(self.h), "fos_fista_grad_dual")
             else:
                 _lib.check(self.lib.fos_fista_grad(self.h), "fos_fista_grad")
 
     def update(self):
-        with torch.cuda.device(self.prob.device):
+        with self.prob.ctx():
             _lib.check(self.lib.fos_fista_update(self.h), "fos_fista_update")
 
     def trial(self, t, with_residual=True):
         out = (C.c_double * 8)()
-        with torch.cuda.device(self.prob.device):
+        with self.prob.ctx():
             _lib.check(self.lib.fos_fista_trial(self.h, float(t), int(bool(with_residual)), out), "fos_fista_trial")
         keys = ("gd", "dd", "nnz", "gnorm2", "y2", "q", "rr_y")
         return dict(zip(keys, list(out)))
@@ -348,7 +361,7 @@ class Fista:
         """Candidates t*eta^j, j < nv, decided by one MFMA pass over A; list of dicts like trial().  None when the
         problem runs the two-pass fallback."""
         out = (C.c_double * (8 * nv))()
-        with torch.cuda.device(self.prob.device):
+        with self.prob.ctx():
             rc = self.lib.fos_fista_trial_batch(self.h, float(t), float(eta), int(nv), out)
         if rc == -4:
             return None
@@ -358,14 +371,14 @@ class Fista:
 
     def status(self):
         st = _lib.FistaStatus()
-        with torch.cuda.device(self.prob.device):
+        with self.prob.ctx():
             _lib.check(self.lib.fos_fista_status_get(self.h, C.byref(st)), "fos_fista_status_get")
         return st
 
     def x_tensor(self):
         """Copy of x_k as a float64 device tensor."""
         out = torch.empty(self.prob.n_dev, dtype=torch.float64, device=self.prob.device)
-        with torch.cuda.device(self.prob.device):
+        with self.prob.ctx():
             _lib.check(self.lib.fos_fista_get_x(self.h, ptr(out)), "fos_fista_get_x")
         return self.prob.vec_out(out)
 
@@ -375,7 +388,7 @@ def run_multi(handles, iters):
     Returns False when this shape / configuration has no multi-vector kernel (callers then run them one by one)."""
     lib = handles[0].lib
     arr = (C.c_void_p * len(handles))(*[h.h for h in handles])
-    with torch.cuda.device(handles[0].prob.device):
+    with handles[0].prob.ctx():
         rc = lib.fos_fista_run_multi(arr, len(handles), int(iters))
     if rc == -4:
         return False

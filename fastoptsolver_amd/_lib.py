@@ -16,7 +16,7 @@ PLAN_NO_RESIDENT, PLAN_NO_TALL, PLAN_NO_WIDE = 1, 2, 4
 class FistaParams(C.Structure):
     _fields_ = [("tau", C.c_double), ("alpha1", C.c_double), ("alpha2", C.c_double), ("delta", C.c_double),
                 ("restart_threshold", C.c_double), ("tol_step", C.c_double), ("tol_ratio", C.c_double),
-                ("mode", C.c_int32), ("prox_kind", C.c_int32), ("adaptive_restart", C.c_int32),
+                ("tol_grad", C.c_double), ("mode", C.c_int32), ("prox_kind", C.c_int32), ("adaptive_restart", C.c_int32),
                 ("reserved", C.c_int32)]
 
 
@@ -39,6 +39,7 @@ SIGNATURES = {
     "fos_problem_plan": (_i32, [_vp, C.POINTER(C.c_int32)]),
     "fos_problem_tune": (_i32, [_vp, _i32, _i32, _i32, _i32]),
     "fos_problem_set_gbuf": (_i32, [_vp, _vp]),
+    "fos_problem_set_stream": (_i32, [_vp, _vp]),
     "fos_problem_replan": (_i32, [_vp, C.c_uint]),
     "fos_comm_unique_id": (_i32, [C.c_char_p]),
     "fos_comm_create": (_i32, [C.POINTER(_vp), C.c_char_p, _i32, _i32]),
@@ -58,6 +59,7 @@ SIGNATURES = {
     "fos_prox_l1": (_i32, [_vp, _f32, _vp, _i64, _vp]),
     "fos_prox_l1_vec": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "fos_prox_elastic_net": (_i32, [_vp, _f32, _f32, _f32, _vp, _i64, _vp]),
+    "fos_prox_elastic_net_vec": (_i32, [_vp, _vp, _f32, _f32, _vp, _i64, _vp]),
     "fos_fista_create": (_i32, [_vp, C.POINTER(_vp)]),
     "fos_fista_destroy": (_i32, [_vp]),
     "fos_fista_reset": (_i32, [_vp, C.POINTER(FistaParams), _vp]),

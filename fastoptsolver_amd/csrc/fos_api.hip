@@ -256,7 +256,9 @@ struct fos_problem {
   double* rr_dd = nullptr;
   int dd_two_pass_chunks = 0;        // > 0: this shape runs the fp64 two-pass kernels for the dd pass
   float* ybuf = nullptr;             // n floats: aligned copy of a caller vector when needed
-  double* dscal = nullptr;           // 128 device doubles (scalars, power-iteration history)
+  double* dscal = nullptr;           // 256 device doubles (scalars)
+  double* lhist = nullptr;           // power iteration: L after every step (n_iter + 1 doubles, grown on demand)
+  int lhist_cap = 0;
   double* part = nullptr;            // partial sums of the small kernels
   int part_cap = 0;
   // batched (MFMA) residual: permuted candidate block, per-workgroup partials, folded results
@@ -730,6 +732,21 @@ int fos_problem_set_comm(fos_problem* p, fos_comm* c) {
   return FOS_OK;
 }
 
+int fos_problem_set_stream(fos_problem* p, void* stream) {
+  if (!p) return fail(FOS_ERR_ARG, "fos_problem_set_stream: null");
+  hipStream_t ns = reinterpret_cast<hipStream_t>(stream);
+  if (ns == p->stream) return FOS_OK;
+  // work already enqueued on the old stream touches the handle's workspace: the new stream waits for it
+  hipEvent_t ev;
+  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, p->stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(ns, ev, 0);
+  (void)hipEventDestroy(ev);
+  if (e != hipSuccess) return fail(FOS_ERR_HIP, std::string("fos_problem_set_stream: ") + hipGetErrorString(e));
+  p->stream = ns;
+  return FOS_OK;
+}
+
 int fos_problem_replan(fos_problem* p, unsigned flags) {
   if (!p) return fail(FOS_ERR_ARG, "fos_problem_replan: null");
   if (flags & ~(unsigned)(FOS_PLAN_NO_RESIDENT | FOS_PLAN_NO_TALL | FOS_PLAN_NO_WIDE))
@@ -768,7 +785,7 @@ int fos_problem_destroy(fos_problem* p) {
   if (!p) return FOS_OK;
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   void* bufs[] = {p->slabs, p->rr_part, p->rr2_part, p->rvec, p->gbuf_own, p->ybuf, p->dscal, p->part, p->xp, p->q_part, p->bt_out,
-                  p->slabs_dd, p->rr_dd};
+                  p->slabs_dd, p->rr_dd, p->lhist};
   for (void* q : bufs)
     if (q) (void)hipFree(q);
   delete p;
@@ -928,9 +945,15 @@ int fos_residual_batch(fos_problem* p, const float* X, int nv, int use_b, double
 }
 
 int fos_power_iter(fos_problem* p, float* v_inout, int n_iter, double tol, double* L_out, int* iters_out) {
-  if (!p || !v_inout || !L_out || n_iter <= 0 || n_iter > 200)
-    return fail(FOS_ERR_ARG, "fos_power_iter: bad argument (n_iter must be 1..200)");
-  double* Lh = p->dscal + 32;   // n_iter + 1 slots
+  if (!p || !v_inout || !L_out || n_iter <= 0) return fail(FOS_ERR_ARG, "fos_power_iter: bad argument");
+  if (n_iter + 1 > p->lhist_cap) {             // L after every step (+ the norm of v0): sized by the caller's n_iter
+    if (p->lhist) (void)hipFree(p->lhist);
+    p->lhist = nullptr;
+    p->lhist_cap = 0;
+    HIP_TRY(hipMalloc(&p->lhist, (size_t)(n_iter + 1) * sizeof(double)));
+    p->lhist_cap = n_iter + 1;
+  }
+  double* Lh = p->lhist;        // n_iter + 1 slots
   if (p->resident) {
     // all iterations in one launch; the break rule (:57) is evaluated on the device
     int* used_dev = reinterpret_cast<int*>(p->dscal + 240);
@@ -1014,6 +1037,16 @@ int fos_prox_elastic_net(const float* v, float tau, float alpha1, float alpha2, 
   return FOS_OK;
 }
 
+int fos_prox_elastic_net_vec(const float* v, const float* tau, float alpha1, float alpha2, float* out, int64_t n,
+                             void* stream) {
+  if (n == 0) return FOS_OK;
+  if (!v || !tau || !out || n < 0) return fail(FOS_ERR_ARG, "fos_prox_elastic_net_vec: bad argument");
+  hipLaunchKernelGGL(fos::prox_enet_vec_kernel, dim3(grid_1d(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, v, tau,
+                     alpha1, alpha2, out, n);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
 // ---- FISTA ---------------------------------------------------------------------------------------------
 int fos_fista_create(fos_problem* p, fos_fista** out) {
   if (!p || !out) return fail(FOS_ERR_ARG, "fos_fista_create: null");
@@ -1056,13 +1089,15 @@ static void to_dev_params(const fos_fista_params* s, fos::FistaParams* d) {
   d->restart_threshold = s->restart_threshold;
   d->tol_step = s->tol_step;
   d->tol_ratio = s->tol_ratio;
+  d->tol_grad = s->tol_grad;
   d->pad = 0;
 }
 
 int fos_fista_reset(fos_fista* f, const fos_fista_params* prm, const double* x0) {
   if (!f || !prm) return fail(FOS_ERR_ARG, "fos_fista_reset: null");
-  if (prm->mode < 0 || prm->mode > 2 || prm->prox_kind < 0 || prm->prox_kind > 1 || !(prm->tau > 0.0))
-    return fail(FOS_ERR_ARG, "fos_fista_reset: bad mode/prox_kind/tau");
+  if (prm->mode < 0 || prm->mode > 2 || prm->prox_kind < 0 || prm->prox_kind > 1 || !(prm->tau > 0.0) ||
+      prm->tol_grad < 0.0 || prm->tol_step < 0.0 || prm->tol_ratio < 0.0)
+    return fail(FOS_ERR_ARG, "fos_fista_reset: bad mode/prox_kind/tau/tolerance");
   to_dev_params(prm, &f->prm);
   fos_problem* p = f->p;
   const size_t nb = (size_t)p->n * sizeof(double);
@@ -1073,11 +1108,8 @@ int fos_fista_reset(fos_fista* f, const fos_fista_params* prm, const double* x0)
     HIP_TRY(hipMemsetAsync(f->x_cur, 0, nb, p->stream));
     HIP_TRY(hipMemsetAsync(f->x_prev, 0, nb, p->stream));
   }
-  fos::FistaScalars init{};
-  init.t_prev = 1.0;
-  init.ratio = INFINITY;
-  HIP_TRY(hipMemcpyAsync(f->scal, &init, sizeof(init), hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(hipStreamSynchronize(p->stream));   // `init` is a stack object
+  hipLaunchKernelGGL(fos::fista_init_scalars_kernel, dim3(1), dim3(1), 0, p->stream, f->scal);
+  LAUNCH_CHECK();
   f->host_valid = true;
   f->y_valid = false;
   f->pending = false;
@@ -1161,7 +1193,16 @@ static int flush_pending(fos_fista* f) {
 
 static bool plain_run(const fos_fista* f) {
   return !(f->prm.mode == fos::MODE_FISTA && f->prm.adaptive_restart) && f->prm.tol_step == 0.0 &&
-         f->prm.tol_ratio == 0.0;
+         f->prm.tol_ratio == 0.0 && f->prm.tol_grad == 0.0;
+}
+
+// The gradient-norm stop sits between the reduced gradient and the update (fos_fista_params.tol_grad).
+static int launch_grad_norm_stop(fos_fista* f) {
+  fos_problem* p = f->p;
+  hipLaunchKernelGGL(fos::grad_norm_stop_kernel, dim3(1), dim3(1024), 0, p->stream, p->gbuf, (int)p->n, f->x_cur, f->x_prev,
+                     f->scal, f->prm);
+  LAUNCH_CHECK();
+  return FOS_OK;
 }
 
 static int refresh_host_scalars(fos_fista* f, bool* stopped) {
@@ -1179,6 +1220,7 @@ static int refresh_host_scalars(fos_fista* f, bool* stopped) {
 // Whole run in ONE launch of ONE workgroup (resident.hpp): A, b and the iterate state stay in LDS.
 static int run_resident(fos_fista* f, int iters, double* x_hist, double* hist, fos::ResidentOpts opt = fos::ResidentOpts{}) {
   fos_problem* p = f->p;
+  if (opt.grad_tol == 0.0) opt.grad_tol = f->prm.tol_grad;     // the handle's own gradient-norm stop (:179)
   int rc = flush_pending(f);                   // device scalars must be current: the kernel continues from them
   if (rc) return rc;
   const bool small = p->n <= fos::RS_CHUNK && p->m <= fos::RS_SMALL_M;    // rows of A in registers (resident.hpp)
@@ -1287,6 +1329,16 @@ int fos_fista_run(fos_fista* f, int iters) {
   fos_problem* p = f->p;
   if (iters == 0) return FOS_OK;
   if (p->resident) return run_resident(f, iters, nullptr, nullptr);
+  if (f->prm.tol_grad > 0.0 && !p->comm) {
+    // gradient-norm stop: K2 -> slab reduce (gbuf) -> norm check -> update from gbuf -> finalize, all enqueued
+    for (int it = 0; it < iters; ++it) {
+      int rc;
+      if ((rc = fos_fista_grad(f))) return rc;
+      if ((rc = launch_grad_norm_stop(f))) return rc;
+      if ((rc = fos_fista_update(f))) return rc;
+    }
+    return FOS_OK;
+  }
   if (p->comm) {
     // Row-sharded problem: K2 on this rank's rows -> slab reduction -> all-reduce of [gradient ; ||r||^2] (n + 1 floats)
     // -> prox + momentum from the reduced gradient, all enqueued on one stream; every rank applies the identical fp64
@@ -1294,6 +1346,7 @@ int fos_fista_run(fos_fista* f, int iters) {
     for (int it = 0; it < iters; ++it) {
       int rc;
       if ((rc = fos_fista_grad(f))) return rc;
+      if (f->prm.tol_grad > 0.0 && (rc = launch_grad_norm_stop(f))) return rc;
       if ((rc = fos_fista_update(f))) return rc;
     }
     return flush_pending(f);

@@ -46,6 +46,7 @@ struct FistaParams {
   double restart_threshold;
   double tol_step;     // stop when this_step < tol_step   (0 = off)
   double tol_ratio;    // stop when ratio < tol_ratio       (0 = off)
+  double tol_grad;     // stop BEFORE the update when ||grad_smooth(y_k)|| < tol_grad   (0 = off)   iterative_solvers.py:179
   int mode;            // MODE_*
   int prox_kind;       // PROX_*
   int adaptive_restart;
@@ -353,6 +354,42 @@ __global__ __launch_bounds__(64) void fista_finalize_kernel(const double* __rest
   scal->stopped = stop;
 }
 
+// Fresh loop state (fos_fista_reset): t = 1, ratio = inf, everything else 0 - written by the device so that the reset
+// only enqueues.
+__global__ void fista_init_scalars_kernel(FistaScalars* __restrict__ scal) {
+  FistaScalars z{};
+  z.t_prev = 1.0;
+  z.ratio = INFINITY;
+  *scal = z;
+}
+
+// Gradient-norm stop (iterative_solvers.py:179: `if tol > 0 and ||grad|| < tol: break`, checked BEFORE the update, grad of
+// the smooth part at y_k incl. alpha2*y) on the device, so that fista(tol > 0) stays enqueue-only: one workgroup reads the
+// reduced gradient in gbuf and raises the stop flag; the update and finalize kernels behind it are then no-ops.
+__global__ __launch_bounds__(1024) void grad_norm_stop_kernel(const float* __restrict__ gbuf, int n,
+                                                             const double* __restrict__ x_cur,
+                                                             const double* __restrict__ x_prev,
+                                                             FistaScalars* __restrict__ scal, FistaParams prm) {
+  if (scal->stopped != 0) return;
+  __shared__ double ws[16];
+  const double beta = scal->beta;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    double gf = (double)gbuf[i];
+    if (prm.prox_kind == PROX_L1 && prm.alpha2 > 0.0) gf += prm.alpha2 * form_y(x_cur[i], x_prev[i], beta);
+    acc += gf * gf;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < 16; ++i) s += ws[i];
+    scal->gnorm2 = s;
+    if (sqrt(s) < prm.tol_grad) scal->stopped = STOP_GRAD;
+  }
+}
+
 // y = (float)(x_cur + beta (x_cur - x_prev)) as one fp32 vector (entry of a lockstep multi-lambda run).
 __global__ __launch_bounds__(256) void form_y_kernel(const double* __restrict__ x_cur, const double* __restrict__ x_prev,
                                                      double beta, float* __restrict__ y, int64_t n) {
@@ -498,6 +535,13 @@ __global__ __launch_bounds__(256) void prox_enet_kernel(const float* __restrict_
   const float thr = tau * a1, inv = 1.0f + tau * a2;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
     out[i] = soft_threshold(v[i], thr) / inv;
+}
+
+// per-element tau (the reference's expression broadcasts an array-valued tau: prox_operators.py:15-16)
+__global__ __launch_bounds__(256) void prox_enet_vec_kernel(const float* __restrict__ v, const float* __restrict__ tau,
+                                                           float a1, float a2, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = soft_threshold(v[i], tau[i] * a1) / (1.0f + tau[i] * a2);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -154,13 +154,15 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
     host-driven otherwise (grad-norm stop ref:179, backtracking ref:183-197, history ref:224-232)."""
     st = state if state is not None else _core.Fista(prob)      # `state`: a stand-in with the same interface (CPU tests)
     x0_dev = None if x0 is None else _core.to_device_vec(x0, prob.device).double()   # padded by Fista.reset
+    # reducer: split-form sharding - the all-reduce sits between the gradient and the update, so the host drives
+    host_driven = backtracking or history is not None or log is not None or reducer is not None
+    # gradient-norm stop (ref:179): on the device (fos_fista_params.tol_grad) when the run is enqueue-only, by the host
+    # between grad() and update() when the host drives anyway
+    dev_grad_stop = grad_tol_check and tol > 0.0 and not host_driven
     st.reset(tau, alpha1, alpha2, mode=mode, prox_kind=prox_kind, delta=delta, adaptive_restart=adaptive_restart,
              restart_threshold=restart_threshold, tol_step=tol if tol > 0.0 else 0.0,
-             tol_ratio=tol_ratio if tol_ratio > 0.0 else 0.0, x0=x0_dev)
+             tol_ratio=tol_ratio if tol_ratio > 0.0 else 0.0, x0=x0_dev, **({"tol_grad": tol} if dev_grad_stop else {}))
     gtimer = getattr(st, "make_timer", _EventTimer)(grad_call_times)     # stand-in states bring a host timer
-    # reducer: split-form sharding - the all-reduce sits between the gradient and the update, so the host drives
-    host_driven = (backtracking or history is not None or log is not None or (grad_tol_check and tol > 0.0)
-                   or reducer is not None)
     smooth_a2 = alpha2 if (prox_kind == _lib.PROX_L1 and alpha2 > 0) else 0.0
     use_batch = batch_trials
 
@@ -178,9 +180,9 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
                 break
         gtimer.flush()
         if stops_possible:
-            # only the iterations that really ran count as gradient calls
-            k = int(st.status().k)
-            del grad_call_times[k:]
+            # only the iterations that really ran count as gradient calls, plus the gradient whose norm ended the run
+            s_end = st.status()
+            del grad_call_times[int(s_end.k) + (1 if s_end.stopped == _lib.STOP_GRAD else 0):]
         return st
 
     # Small problems (A fits one CU's LDS): every host-driven feature - backtracking, gradient-norm stop, history, ISTA

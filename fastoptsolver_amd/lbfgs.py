@@ -58,7 +58,7 @@ class _HipOps:
                 torch.zeros(cap, self.n, dtype=torch.float64, device=self.dev))
 
     def grad(self, x, a2, g):
-        with torch.cuda.device(self.dev):
+        with self.prob.ctx():
             _lib.check(self.lib.fos_gemv_pair_dd(self.prob.h, _core.ptr(x), float(a2), _core.ptr(g)), "fos_gemv_pair_dd")
         self.rr = g._base[self.n:]
 

@@ -47,6 +47,7 @@ typedef struct fos_fista_params {
   double restart_threshold; /*                                             :210                   */
   double tol_step;          /* stop when ||x_next - x_k|| < tol_step       :238, :337  (0 = off)  */
   double tol_ratio;         /* stop when ratio < tol_ratio                 :242, :341  (0 = off)  */
+  double tol_grad;          /* stop BEFORE the update when ||grad|| < tol_grad   :179   (0 = off)  */
   int32_t mode;             /* FOS_MODE_*                                                         */
   int32_t prox_kind;        /* FOS_PROX_L1: l2 in the gradient; FOS_PROX_ENET: l2 in the prox     */
   int32_t adaptive_restart; /*                                             :209                   */
@@ -75,6 +76,10 @@ int fos_abi_version(void);
 int fos_problem_create(fos_problem** out, const void* A, int64_t m, int64_t n, int64_t lda, int a_dtype,
                        const float* b, void* stream);
 int fos_problem_destroy(fos_problem* p);
+/* Move the handle (and the fos_fista handles on it) to another stream; the new stream first waits for whatever the old
+ * one still has enqueued on the handle's workspace.  The Python layer calls this whenever torch's current stream differs
+ * from the one the handle last ran on, so a prepared problem can be used inside `with torch.cuda.stream(s)`. */
+int fos_problem_set_stream(fos_problem* p, void* stream);
 /* plan[0..7] = {path (0 fused single pass, 1 two-pass fallback), threads, chunks/thread, rows/step,
  *               workgroups, slabs, flags (bit 0: non-temporal loads; bit 1: small enough for the single-launch
  *               LDS-resident loop that fos_fista_run / _run_history / fos_power_iter then use; bit 2: n <= 64, the
@@ -146,18 +151,20 @@ int fos_residual_objective(fos_problem* p, const float* x, double* out3);
 int fos_residual_batch(fos_problem* p, const float* X, int nv, int use_b, double* out16);
 
 /* Power iteration, iterative_solvers.py:45-60.  v_inout: start vector (n floats, need not be normalised),
- * overwritten with the last iterate.  Synchronises; *L_out and *iters_out are host values. */
+ * overwritten with the last iterate.  Any n_iter >= 1.  Synchronises; *L_out and *iters_out are host values. */
 int fos_power_iter(fos_problem* p, float* v_inout, int n_iter, double tol, double* L_out, int* iters_out);
 
 /* ---- stand-alone prox (K3), prox_operators.py:3-8 and :10-16 --------------------------------------- */
 int fos_prox_l1(const float* v, float thr, float* out, int64_t n, void* stream);
 int fos_prox_l1_vec(const float* v, const float* thr, float* out, int64_t n, void* stream);   /* per-element threshold */
 int fos_prox_elastic_net(const float* v, float tau, float alpha1, float alpha2, float* out, int64_t n, void* stream);
+int fos_prox_elastic_net_vec(const float* v, const float* tau, float alpha1, float alpha2, float* out, int64_t n,
+                             void* stream);                                                  /* per-element tau */
 
 /* ---- FISTA / FISTA-delta / ISTA state machine ------------------------------------------------------- */
 int fos_fista_create(fos_problem* p, fos_fista** out);
 int fos_fista_destroy(fos_fista* f);
-/* x_0 = x0 (device, n DOUBLES) or zeros when NULL; t = 1; beta = 0; k = 0.  :149-161, :269-280, :79-81
+/* x_0 = x0 (device, n DOUBLES) or zeros when NULL; t = 1; beta = 0; k = 0.  :149-161, :269-280, :79-81.  Enqueues only.
  * The iterate state x_k, x_{k-1} is fp64 on the device (n-vectors are negligible traffic; an fp32 state alone
  * costs 1e-4 of parity on ill-conditioned data).  y_k is rounded once to fp32 for the pass over A. */
 int fos_fista_reset(fos_fista* f, const fos_fista_params* prm, const double* x0);

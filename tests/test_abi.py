@@ -50,7 +50,7 @@ def test_version_and_error_paths_without_gpu(lib):
 
 def test_struct_layouts_match_header():
     from fastoptsolver_amd import _lib
-    assert ctypes.sizeof(_lib.FistaParams) == 7 * 8 + 4 * 4
+    assert ctypes.sizeof(_lib.FistaParams) == 8 * 8 + 4 * 4          # 8 doubles (incl. tol_grad) + 4 int32
     assert ctypes.sizeof(_lib.FistaStatus) == 10 * 8 + 8 + 2 * 4
 
 
