@@ -807,6 +807,12 @@ int fos_problem_plan(const fos_problem* p, int32_t plan[8]) {
 
 int fos_problem_tune(fos_problem* p, int threads, int chunks, int rows, int workgroups) {
   if (!p) return fail(FOS_ERR_ARG, "fos_problem_tune: null");
+  if (p->path == 0 && p->tall && workgroups > 0) {        // row-per-thread pass: only the workgroup count is tunable
+    p->rows_per_wg = (p->m + workgroups - 1) / workgroups;
+    p->nwg = (int)((p->m + p->rows_per_wg - 1) / p->rows_per_wg);
+    p->nslabs = p->nwg;
+    return ensure_workspace(p);
+  }
   if (p->path != 0 || p->tall)
     return fail(FOS_ERR_UNSUPPORTED, "fos_problem_tune: only the streaming single-pass kernel has a geometry menu");
   const MenuEntry* e = find_entry(p->dtype, threads, chunks, rows);
