@@ -182,6 +182,25 @@ void tallq_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, 
   hipLaunchKernelGGL((fos::gemv_tall_quad_kernel<T, VEC, WITH_G, DUAL>), dim3(nwg), dim3(fos::TL_THREADS), 0, st,
                      reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part, rr2_part);
 }
+template <typename T, int LPR, bool WITH_G, bool DUAL>
+void tallr_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, float* slabs,
+                  double* rr_part, double* rr2_part, int nwg, hipStream_t st) {
+  hipLaunchKernelGGL((fos::gemv_tall_rows_kernel<T, LPR, WITH_G, DUAL>), dim3(nwg), dim3(fos::TL_THREADS), 0, st,
+                     reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part, rr2_part);
+}
+template <typename T, int LPR>
+void tallr_launch_dd(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, double* slabs,
+                     double* rr_part, int nwg, hipStream_t st) {
+  hipLaunchKernelGGL((fos::gemv_tall_rows_kernel<T, LPR, true, false, double>), dim3(nwg), dim3(fos::TL_THREADS), 0, st,
+                     reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part, (double*)nullptr);
+}
+// aligned rows: a row per LPR lanes, one 16-byte chunk per lane (gemv_tall_rows_kernel); k = LPR marks the entry
+#define TALLR(DT, T, LPR) \
+  { DT, fos::TL_THREADS, LPR, 0, tallr_launch<T, LPR, true, false>, tallr_launch<T, LPR, false, false>, \
+    tallr_launch<T, LPR, true, true>, tallr_launch_dd<T, LPR> }
+const MenuEntry kTallRowsF32[3] = {TALLR(FOS_F32, float, 4), TALLR(FOS_F32, float, 8), TALLR(FOS_F32, float, 16)};
+const MenuEntry kTallRowsBf16[2] = {TALLR(FOS_BF16, fos::bf16_t, 4), TALLR(FOS_BF16, fos::bf16_t, 8)};
+#undef TALLR
 // 33..64 columns: a row per quad of lanes (gemv_tall_quad_kernel)
 #define TALLQ(DT, T, VEC) \
   { DT, fos::TL_THREADS, 0, 0, tallq_launch<T, VEC, true, false>, tallq_launch<T, VEC, false, false>, \
@@ -203,6 +222,15 @@ const MenuEntry kTallBf16[4][2] = {
 #undef TALLQ
 // load form: 16-byte row loads when the layout allows, LDS staging for contiguous ragged matrices, scalar loads otherwise
 const MenuEntry* tall_entry(int dtype, int64_t n, int64_t lda, const void* A) {
+  const int epc = dtype == FOS_F32 ? 4 : 8;
+  // Rows of 5..16 chunks of 16 bytes (fp32: 17..64 columns, bf16: 33..64): a row per 8 / 16 lanes, one chunk per lane
+  // (4000000 x 32: 52 % -> 74 % of the roofline, 2000000 x 64: 53 % -> 73 %).  Up to 4 chunks the row-per-thread form
+  // with 16-byte loads is the faster one (4000000 x 16: 72-76 % against 67-69 %, profiles/r02_sweep_wgs.log).
+  if (n % epc == 0 && lda % epc == 0 && (reinterpret_cast<uintptr_t>(A) & 15u) == 0 && n / epc > 4) {
+    const int chunks = (int)(n / epc);
+    if (dtype == FOS_F32) return &kTallRowsF32[chunks <= 8 ? 1 : 2];
+    return &kTallRowsBf16[1];
+  }
   const int idx = n <= 8 ? 0 : n <= 16 ? 1 : n <= 32 ? 2 : 3;
   const bool contiguous = (lda == n);
   if (dtype == FOS_F32) {
@@ -301,8 +329,12 @@ void plan_fused(fos_problem* p, const MenuEntry* e, int nwg_hint) {
   p->entry = e;
   p->path = 0;
   int64_t m = p->m;
-  // one workgroup per CU for the wide geometries (>= 256 threads); 8 single-wave workgroups per CU for the narrow ones
-  int nwg = nwg_hint > 0 ? nwg_hint : p->ncu * (e->threads >= 256 ? 1 : 512 / e->threads);
+  // Workgroups per CU (profiles/r02_sweep_wgs.log): one for the wide geometries, whose register tiles already hold
+  // 64-96 KiB of rows in flight per CU; two for the 256-thread geometries with 1-2 chunks per thread (1048576 x 1024:
+  // 67 % -> 88 % of the roofline - one such workgroup has 32 KiB in flight, below HBM latency x bandwidth per CU);
+  // 16 single-wave workgroups for the one-wave-per-row geometries.
+  const int per_cu = e->threads >= 512 ? 1 : e->threads == 256 ? (e->k <= 2 ? 2 : 1) : 1024 / e->threads;
+  int nwg = nwg_hint > 0 ? nwg_hint : p->ncu * per_cu;
   const int64_t min_rows = 2 * (int64_t)e->r;
   if (m < (int64_t)nwg * min_rows) nwg = (int)std::max<int64_t>(1, m / min_rows);
   p->rows_per_wg = (m + nwg - 1) / nwg;
@@ -317,7 +349,10 @@ void plan_tall(fos_problem* p, const MenuEntry* e) {
   p->tall = true;
   p->slab_stride = fos::tall_slab_stride((int)p->n);
   p->vec4 = true;                    // padded slab rows: the float4 epilogues serve ragged n as well
-  int64_t nwg = std::max<int64_t>(1, std::min<int64_t>(4 * (int64_t)p->ncu, p->m / (4 * fos::TL_THREADS)));
+  // 4 workgroups per CU; 8 for the chunk-per-lane form (17-40 VGPRs: 8 workgroups are resident, each with 4 KiB per
+  // wave in flight) - profiles/r02_sweep_wgs.log
+  const int per_cu = e->k > 0 ? 8 : 4;
+  int64_t nwg = std::max<int64_t>(1, std::min<int64_t>(per_cu * (int64_t)p->ncu, p->m / (4 * fos::TL_THREADS)));
   p->rows_per_wg = (p->m + nwg - 1) / nwg;
   p->nwg = (int)((p->m + p->rows_per_wg - 1) / p->rows_per_wg);
   p->nslabs = p->nwg;
@@ -601,7 +636,7 @@ int ensure_dd(fos_problem* p) {
         if (c.dtype == p->dtype && (int64_t)c.threads * c.k * epc_of(p->dtype) >= p->n) { e = &c; break; }
     if (e) {
       p->dd_entry = e;
-      int nwg = p->ncu * (e->threads >= 256 ? 1 : 512 / e->threads);
+      int nwg = p->ncu * (e->threads >= 512 ? 1 : e->threads == 256 ? (e->k <= 2 ? 2 : 1) : 1024 / e->threads);
       const int64_t min_rows = 2 * (int64_t)e->r;
       if (p->m < (int64_t)nwg * min_rows) nwg = (int)std::max<int64_t>(1, p->m / min_rows);
       p->dd_rows_per_wg = (p->m + nwg - 1) / nwg;

@@ -60,18 +60,32 @@ __global__ __launch_bounds__(TL_THREADS) void gemv_tall_kernel(const T* __restri
   // no other memory-level parallelism than its own rows); 2 where the registers allow (NC <= 16).
   constexpr int RPI = NC <= 16 ? 2 : 1;
   constexpr int BLOCK_ROWS = RPI * TL_THREADS;
-  for (int64_t row0 = row_lo; row0 < row_hi; row0 += BLOCK_ROWS) {          // uniform loop: TL_STAGE needs the barriers
+  // TL_STAGE: the block after the one being consumed is already on its way into registers (its global-load latency
+  // overlaps the LDS reads and the fp64 arithmetic of this one); it moves into LDS between two barriers.
+  float pre[STAGE ? NC * RPI : 1];
+  auto prefetch = [&](int64_t row0) {
     if constexpr (STAGE) {
       const int64_t left = row_hi - row0;
-      const int count = (int)(left < BLOCK_ROWS ? left : BLOCK_ROWS) * n;
+      const int count = left <= 0 ? 0 : (int)(left < BLOCK_ROWS ? left : BLOCK_ROWS) * n;
       const T* src = A + row0 * (int64_t)n;                              // lda == n: the block is one contiguous span
+#pragma unroll
+      for (int u = 0; u < NC * RPI; ++u) {
+        const int i = u * TL_THREADS + tid;
+        pre[u] = i < count ? elem_to_float<T>(src[i]) : 0.f;
+      }
+    }
+  };
+  prefetch(row_lo);
+  for (int64_t row0 = row_lo; row0 < row_hi; row0 += BLOCK_ROWS) {          // uniform loop: TL_STAGE needs the barriers
+    if constexpr (STAGE) {
       __syncthreads();                                                   // the previous block has been consumed
 #pragma unroll
       for (int u = 0; u < NC * RPI; ++u) {
         const int i = u * TL_THREADS + tid;
-        if (i < count) tile_s[i] = elem_to_float<T>(src[i]);
+        if (i < BLOCK_ROWS * n) tile_s[i] = pre[u];
       }
       __syncthreads();
+      prefetch(row0 + BLOCK_ROWS);
     }
     float a[RPI][NC];
     double bi[RPI];
@@ -240,6 +254,131 @@ __global__ __launch_bounds__(TL_THREADS) void gemv_tall_quad_kernel(const T* __r
       const int sb = tid / TQ_CPL, c = tid % TQ_CPL;
       double tot = 0.0;
       for (int k = 0; k < TQ_ROWS; ++k) tot += gred[4 * k + sb][c];
+      if (tid < sstride) slabs[(int64_t)blockIdx.x * sstride + tid] = tid < n ? (ST)tot : (ST)0;
+    }
+  }
+  double tail[8] = {rr, rr2, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  wave_sum_n(tail);
+  if (lane == 0) { red[wave][0] = tail[0]; red[wave][1] = tail[1]; }
+  __syncthreads();
+  if (tid == 0) {
+    rr_part[blockIdx.x] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    if constexpr (DUAL) rr2_part[blockIdx.x] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Aligned tall-skinny rows (n <= 64, n and lda multiples of 16 bytes, A 16-byte aligned): a row per LPR lanes, every
+// lane owns ONE 16-byte chunk of the row (4 fp32 / 8 bf16 columns).  A wave's load instruction then reads 64 consecutive
+// chunks = 1 KiB of contiguous memory when lda == n (the row-per-thread and row-per-quad forms above touch 16 bytes of 64
+// different rows / a quarter of every line per instruction and reach 52 % / 53 % of the roofline at n = 32 / 64), the
+// per-lane state is 4-8 columns of y and of the gradient instead of 16-64, and U row steps are in flight per lane.
+// The row dot is a butterfly over the LPR lanes on the DPP path (quad_perm, row_half_mirror, row_mirror: every lane of
+// the row ends with the total, no broadcast step).  fp64 accumulation like the other tall kernels.
+// Output contract = gemv_tall_kernel.
+// ---------------------------------------------------------------------------------------------------------
+template <int LPR>
+__device__ inline double lanes_sum(double v) {
+  static_assert(LPR == 4 || LPR == 8 || LPR == 16, "LPR");
+  v += dpp_fetch<0xB1, 0xF>(v);                         // quad_perm [1,0,3,2]
+  v += dpp_fetch<0x4E, 0xF>(v);                         // quad_perm [2,3,0,1]
+  if constexpr (LPR >= 8) v += dpp_fetch<0x141, 0xF>(v);   // row_half_mirror
+  if constexpr (LPR >= 16) v += dpp_fetch<0x140, 0xF>(v);  // row_mirror
+  return v;
+}
+
+template <typename T, int LPR, bool WITH_G, bool DUAL, typename ST = float>
+__global__ __launch_bounds__(TL_THREADS) void gemv_tall_rows_kernel(const T* __restrict__ A, int64_t lda,
+                                                                   const float* __restrict__ b, int64_t m, int n, YSource ys,
+                                                                   int64_t rows_per_wg, ST* __restrict__ slabs,
+                                                                   double* __restrict__ rr_part, double* __restrict__ rr2_part) {
+  using Tr = ElemTraits<T>;
+  constexpr int EPL = Tr::EPC;                  // columns per lane (one 16-byte chunk)
+  constexpr int RPS = TL_THREADS / LPR;         // rows per step of the workgroup
+  constexpr int U = 4;                          // row steps in flight per lane (8 measured the same: r02_sweep_wgs)
+  constexpr int NW = TL_THREADS / 64;
+  __shared__ double gred[WITH_G ? TL_THREADS : 1][EPL];
+  __shared__ double red[NW][2];
+  if (ys.stopped != nullptr && *ys.stopped != 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = tid % LPR, rslot = tid / LPR;
+  const int cbase = sub * EPL;
+  const bool live = cbase < n;                  // n % EPL == 0: a chunk is inside the row or outside it entirely
+  const double beta = source_beta(ys);
+  double yv[EPL], xv[DUAL ? EPL : 1], g[WITH_G ? EPL : 1];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    yv[e] = live ? source_y(ys, cbase + e, beta) : 0.0;
+    if constexpr (DUAL) xv[e] = live ? ys.x_cur[cbase + e] : 0.0;
+    if constexpr (WITH_G) g[e] = 0.0;
+  }
+  double rr = 0.0, rr2 = 0.0;
+  const int64_t row_lo = (int64_t)blockIdx.x * rows_per_wg;
+  int64_t row_hi = row_lo + rows_per_wg;
+  if (row_hi > m) row_hi = m;
+  // Branch-free loads (rows past the end re-read the last row, lanes past n re-read chunk 0; both are masked when
+  // consumed), two register sets: the loads of the next U row steps are in flight while this set is consumed, and the
+  // compiler can wait with a counted vmcnt (gemv_pair.hpp "Software pipeline").
+  const char* base = reinterpret_cast<const char*>(A) + (live ? (size_t)cbase * sizeof(T) : 0);
+  const int64_t row_bytes = lda * (int64_t)sizeof(T);
+  const float* b_src = b != nullptr ? b : reinterpret_cast<const float*>(A);
+  constexpr int STEP = U * RPS;
+  auto issue = [&](u32x4 (&raw)[U], float (&bi)[U], int64_t row0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t row = row0 + u * RPS + rslot;
+      if (row >= row_hi) row = row_hi - 1;
+      raw[u] = load16<true>(base + row * row_bytes);
+      bi[u] = b_src[b != nullptr ? row : 0];
+    }
+  };
+  auto consume = [&](const u32x4 (&raw)[U], const float (&bi)[U], int64_t row0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool in = (row0 + u * RPS + rslot < row_hi) && live;
+      float a[EPL];
+      Tr::unpack(raw[u], a);
+      double acc = 0.0, acc2 = 0.0;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        a[e] = in ? a[e] : 0.f;                  // masked rows / lanes: a = 0 -> no contribution to the dot or to g
+        acc = fma((double)a[e], yv[e], acc);
+        if constexpr (DUAL) acc2 = fma((double)a[e], xv[e], acc2);
+      }
+      const bool row_in = row0 + u * RPS + rslot < row_hi;
+      const double bv = (row_in && b != nullptr) ? (double)bi[u] : 0.0;
+      acc = lanes_sum<LPR>(acc) - bv;
+      if (sub == 0 && row_in) rr += acc * acc;
+      if constexpr (DUAL) {
+        acc2 = lanes_sum<LPR>(acc2) - bv;
+        if (sub == 0 && row_in) rr2 += acc2 * acc2;
+      }
+      if constexpr (WITH_G) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) g[e] = fma((double)a[e], acc, g[e]);
+      }
+    }
+  };
+  if (row_lo < row_hi) {
+    u32x4 rawA[U], rawB[U];
+    float biA[U], biB[U];
+    issue(rawA, biA, row_lo);
+    for (int64_t row0 = row_lo; row0 < row_hi; row0 += 2 * STEP) {
+      issue(rawB, biB, row0 + STEP);
+      consume(rawA, biA, row0);
+      issue(rawA, biA, row0 + 2 * STEP);
+      consume(rawB, biB, row0 + STEP);
+    }
+  }
+  const int sstride = tall_slab_stride(n);
+  if constexpr (WITH_G) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) gred[tid][e] = g[e];
+    __syncthreads();
+    if (tid < LPR * EPL) {                       // column tid: held by the lanes with sub == tid / EPL, one per row slot
+      const int sb = tid / EPL, e = tid % EPL;
+      double tot = 0.0;
+      for (int k = 0; k < RPS; ++k) tot += gred[k * LPR + sb][e];
       if (tid < sstride) slabs[(int64_t)blockIdx.x * sstride + tid] = tid < n ? (ST)tot : (ST)0;
     }
   }

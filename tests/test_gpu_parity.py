@@ -986,7 +986,10 @@ def test_resident_loop_with_bf16_storage(fos):
 # --------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m,n,kind", [(20000, 5, "f32"), (20001, 7, "f32"), (70000, 8, "f32"), (33333, 16, "f32"),
                                       (9000, 33, "f32"), (12345, 64, "f32"), (5000, 32, "strided"), (6000, 12, "bf16"),
-                                      (200, 64, "f32"), (1, 40, "f32")])
+                                      (200, 64, "f32"), (1, 40, "f32"),
+                                      # aligned rows: a row per 4 / 8 / 16 lanes, one 16-byte chunk per lane
+                                      (40001, 12, "f32"), (30000, 24, "f32"), (25000, 40, "f32"), (1027, 60, "f32"),
+                                      (7000, 48, "strided"), (9000, 16, "bf16"), (8000, 40, "bf16"), (5003, 64, "bf16")])
 def test_tall_skinny_gemv_pair(fos, m, n, kind):
     rng = np.random.default_rng(m + n)
     A = rng.standard_normal((m, n)).astype(np.float32)
@@ -1010,6 +1013,19 @@ def test_tall_skinny_gemv_pair(fos, m, n, kind):
     assert rr == pytest.approx(rr_ref, rel=1e-6) and x1 == pytest.approx(np.abs(y.astype(np.float64)).sum(), rel=1e-6)
     # deterministic: bit-identical across launches
     assert torch.equal(prob.gemv_pair(_dev(y), alpha2=0.3), prob.gemv_pair(_dev(y), alpha2=0.3))
+    # the fp64 form of the same kernel (L-BFGS fg) and the DUAL form (history objective from the gradient pass)
+    from fastoptsolver_amd import _core, _lib
+    out = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
+    yd = _dev(y, torch.float64)
+    _lib.check(_lib.load().fos_gemv_pair_dd(prob.h, _core.ptr(yd), 0.3, _core.ptr(out)))
+    assert _data.rel(out[:n].cpu().numpy(), g_ref) < 1e-12 and float(out[n]) == pytest.approx(rr_ref, rel=1e-12)
+    if m >= 1000:
+        lam = float(np.max(np.abs(A.T.astype(np.float64) @ b)))
+        L = float(np.linalg.norm(A.astype(np.float64), 2) ** 2)
+        x, h = fos.fista(prob, None, "lasso", 0.05 * lam, 0.0, max_iter=12, L=L, return_history=True, adaptive_restart=True)
+        x_ref, h_ref = orc.fista(A.astype(np.float64), b.astype(np.float64), "lasso", 0.05 * lam, 0.0, max_iter=12, L=L,
+                                 return_history=True, adaptive_restart=True)
+        assert _data.rel(_np(x), x_ref) < TOL and np.allclose(h["obj"], h_ref["obj"], rtol=TOL)
 
 
 def test_tall_skinny_solvers_on_unstandardised_features(fos):
