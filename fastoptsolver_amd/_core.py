@@ -384,7 +384,7 @@ class Fista:
 
 
 def run_multi(handles, iters):
-    """Advance up to 4 Fista handles of one Problem in lockstep (one pass over A per iteration for all of them).
+    """Advance up to 16 Fista handles of one Problem in lockstep (fos_fista_run_multi).
     Returns False when this shape / configuration has no multi-vector kernel (callers then run them one by one)."""
     lib = handles[0].lib
     arr = (C.c_void_p * len(handles))(*[h.h for h in handles])

@@ -44,6 +44,9 @@ SIGNATURES = {
     "fos_comm_unique_id": (_i32, [C.c_char_p]),
     "fos_comm_create": (_i32, [C.POINTER(_vp), C.c_char_p, _i32, _i32]),
     "fos_comm_destroy": (_i32, [_vp]),
+    "fos_comm_mesh_create": (_i32, [C.POINTER(_vp), _i32, _i32, _i64, C.c_char_p]),
+    "fos_comm_mesh_connect": (_i32, [_vp, C.c_char_p]),
+    "fos_comm_check": (_i32, [_vp, _vp]),
     "fos_comm_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "fos_comm_transport": (C.c_char_p, []),
     "fos_comm_allreduce": (_i32, [_vp, _vp, _i64, _i32, _vp]),

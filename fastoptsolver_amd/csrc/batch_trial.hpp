@@ -21,7 +21,6 @@
 
 namespace fos {
 
-constexpr int BT_NV = 16;            // candidates per pass (MFMA N)
 constexpr int BT_ROWS = 64;          // rows per tile  (4 waves x 16)
 #ifndef FOS_BT_COLS
 #define FOS_BT_COLS 64
@@ -33,14 +32,6 @@ constexpr int BT_F4_ROW = BT_COLS / 4;                               // float4 p
 constexpr int BT_A_LOADS = BT_ROWS * BT_F4_ROW / BT_THREADS;         // float4 of A per thread per tile
 constexpr int BT_X_LOADS = BT_COLS * BT_NV / 4 / BT_THREADS;         // float4 of the candidate block per thread per tile
 constexpr int BT_W = 3 * BT_NV + 2;  // per-workgroup outputs of the candidate kernel
-
-// X block layout ("Xp"): for column k and candidate j,
-//   Xp[ ((k/16)*4 + (k%16)/4) * 64 + j*4 + (k%4) ]
-// i.e. per 16-column subtile a [q = 4][j = 16][c = 4] cube: the float4 a lane needs for one subtile is contiguous and
-// the 64 lanes of a wave read 1 KiB contiguous.
-__device__ __host__ inline int64_t xp_index(int64_t k, int j) {
-  return ((k / 16) * 4 + (k % 16) / 4) * 64 + (int64_t)j * 4 + (k % 4);
-}
 
 static_assert(BT_COLS % 16 == 0 && BT_A_LOADS >= 1 && BT_X_LOADS >= 1, "tile shape");
 
@@ -104,13 +95,16 @@ __global__ __launch_bounds__(256) void fista_trial_batch_kernel(const float* __r
 
 // q_part[wg][j] = sum over this workgroup's rows of (A_i . X_j - use_b * b_i)^2.
 // Requirements (host-checked): n % 4 == 0, lda % 4 == 0, A 16-byte aligned, Xp zero-padded to n_pad = 64*ceil(n/64).
-template <int RB>
+// STORE_R = true (multi-lambda gradient, gram_batch.hpp): the residuals themselves, rout[row][16 candidates] fp32,
+// are kept for the second product G = A^T R.
+template <int RB, bool STORE_R = false>
 __global__ __launch_bounds__(BT_THREADS) void residual_batch_mfma_kernel(const float* __restrict__ A, int64_t lda,
                                                                         const float* __restrict__ b, int use_b,
                                                                         int64_t m, int n,
                                                                         const float* __restrict__ xp,
                                                                         int64_t groups_per_wg,
-                                                                        double* __restrict__ q_part) {
+                                                                        double* __restrict__ q_part,
+                                                                        float* __restrict__ rout = nullptr) {
   constexpr int ROWS = BT_ROWS * RB;              // RB 16-row blocks per wave share each candidate fragment read
   constexpr int A_LOADS = BT_A_LOADS * RB;
   __shared__ __attribute__((aligned(16))) float a_s[2][ROWS][BT_LDS_STRIDE];
@@ -188,6 +182,7 @@ __global__ __launch_bounds__(BT_THREADS) void residual_batch_mfma_kernel(const f
             float v = acc[rb][r];
             if (use_b) v -= b[row];
             qsum += (double)v * (double)v;
+            if constexpr (STORE_R) rout[row * BT_NV + (lane & 15)] = v;      // 16 lanes: one 64-byte row of R
           }
         }
         acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -246,16 +241,6 @@ __global__ __launch_bounds__(BT_THREADS) void residual_batch_mfma_kernel(const f
 // =========================================================================================================
 constexpr int BQ_COLS = 128;                         // Xq is zero-padded to a multiple of this many columns
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __host__ inline int64_t xq_index(int64_t k, int j, int part) {
-  return (((k / 32) * 3 + part) * 4 + (k % 32) / 8) * 128 + (int64_t)j * 8 + (k % 8);
-}
-
-__device__ inline unsigned short f32_to_bf16_rn(float f) {
-  const unsigned u = __float_as_uint(f);
-  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);      // finite inputs only (differences of iterates)
-}
-__device__ inline float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
 // Candidate generation for the bf16 path: same sums as fista_trial_batch_kernel, dlt_j written as three bf16 terms.
 __global__ __launch_bounds__(256) void fista_trial_batch_bf16_kernel(const float* __restrict__ gbuf, int n, int n_pad,
@@ -337,10 +322,11 @@ __global__ void xq_pack_kernel(const float* __restrict__ X, int n, int n_pad, in
 // RB = 16-row blocks per wave (the candidate fragments read from LDS are reused for RB row blocks: X is 96 bytes per
 // column against 32 bytes of A per row block, so LDS traffic per byte of A falls with RB); COLS = bf16 columns per tile.
 // Requirements: n % 8 == 0, lda % 8 == 0, A 16-byte aligned, Xq zero-padded to n_pad (a multiple of 128).
-template <int RB, int COLS>
+template <int RB, int COLS, bool STORE_R = false>
 __global__ __launch_bounds__(BT_THREADS) void residual_batch_mfma_bf16_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const float* __restrict__ b, int use_b, int64_t m, int n,
-    const unsigned short* __restrict__ xq, int64_t groups_per_wg, double* __restrict__ q_part) {
+    const unsigned short* __restrict__ xq, int64_t groups_per_wg, double* __restrict__ q_part,
+    float* __restrict__ rout = nullptr) {
   constexpr int ROWS = 64 * RB;
   constexpr int STRIDE = COLS + 8;
   constexpr int CPR = COLS / 8;                               // 16-byte chunks per tile row
@@ -426,6 +412,7 @@ __global__ __launch_bounds__(BT_THREADS) void residual_batch_mfma_bf16_kernel(
             float v = acc[rb][r];
             if (use_b) v -= b[row];
             qsum += (double)v * (double)v;
+            if constexpr (STORE_R) rout[row * BT_NV + (lane & 15)] = v;
           }
         }
         acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};

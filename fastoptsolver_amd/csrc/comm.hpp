@@ -59,8 +59,92 @@ inline const RcclApi* rccl_api(std::string* err) {
 
 }  // namespace fos
 
+namespace fos {
+
+// ---- one-shot full-mesh all-reduce ----------------------------------------------------------
+// The exchange of a sharded iteration is n + 1 floats (64 KiB): a ring all-reduce spends 2(P-1) latency-bound steps on it.
+// xGMI is a full mesh of point-to-point links, so every rank can instead WRITE its vector straight into an inbox on every
+// peer (one hop, all links busy at once) and each rank sums the P inbox rows itself, in rank order - one kernel, one
+// network latency, and bit-identical results on all ranks by construction (same numbers, same order).
+//   inbox  [2 sets][P sources][cap bytes]   on every rank, IPC-mapped into the peers (hipIpcGetMemHandle)
+//   flags  [2 sets][P sources][MESH_MAXWG]  sequence numbers: "source s has delivered slice w of all-reduce #seq"
+// Workgroup w owns a slice of the vector: push the slice to all peers, fence (system scope), publish the flags, wait for
+// the P flags of its own slice (bounded spin on the 100 MHz wall clock: a lost peer ends the kernel with an error flag
+// instead of hanging the GPU), sum.  Two inbox sets alternate: a rank can be at most one all-reduce ahead of the slowest.
+// All inbox / flag traffic uses system-scope atomics (sc0 sc1: no stale L2 lines on either side of the link).
+constexpr int MESH_MAXWG = 32;
+constexpr int MESH_MAXRANKS = 8;
+constexpr int MESH_THREADS = 256;
+
+struct MeshPeers {
+  char* inbox[MESH_MAXRANKS];                 // inbox base of every rank (own entry: the local allocation)
+  unsigned long long* flags[MESH_MAXRANKS];
+};
+
+template <typename T>
+__global__ __launch_bounds__(MESH_THREADS) void mesh_allreduce_kernel(MeshPeers peers, int nranks, int rank, T* __restrict__ buf,
+                                                                     long long count, unsigned long long seq,
+                                                                     long long cap_elems, unsigned long long timeout_ticks,
+                                                                     int* __restrict__ err) {
+  const int set = (int)(seq & 1ull);
+  const int w = blockIdx.x, tid = threadIdx.x;
+  const long long per = (count + gridDim.x - 1) / gridDim.x;
+  const long long lo = (long long)w * per;
+  long long hi = lo + per;
+  if (hi > count) hi = count;
+  // 1. push this slice into every rank's inbox row [set][rank]
+  for (int p = 0; p < nranks; ++p) {
+    T* dst = reinterpret_cast<T*>(peers.inbox[p]) + ((long long)(set * nranks + rank)) * cap_elems;
+    for (long long i = lo + tid; i < hi; i += MESH_THREADS)
+      __hip_atomic_store(dst + i, buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_system();
+  __syncthreads();
+  // 2. publish: "rank has delivered slice w of all-reduce #seq" to every rank
+  if (tid < nranks)
+    __hip_atomic_store(peers.flags[tid] + ((long long)(set * nranks + rank)) * MESH_MAXWG + w, seq, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  // 3. wait for slice w of every source (bounded)
+  __shared__ int bad;
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  if (tid < nranks) {
+    const unsigned long long* f = peers.flags[rank] + ((long long)(set * nranks + tid)) * MESH_MAXWG + w;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+      if (wall_clock64() - t0 > timeout_ticks) { bad = 1; break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __syncthreads();
+  if (bad) {
+    if (tid == 0) *err = 1;
+    return;                                   // buf keeps this rank's partial: the host reports the failure
+  }
+  // 4. sum the P inbox rows of this slice in rank order
+  const T* rows = reinterpret_cast<const T*>(peers.inbox[rank]) + ((long long)set * nranks) * cap_elems;
+  for (long long i = lo + tid; i < hi; i += MESH_THREADS) {
+    T s = (T)0;
+    for (int src = 0; src < nranks; ++src)
+      s += __hip_atomic_load(rows + (long long)src * cap_elems + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    buf[i] = s;
+  }
+}
+
+}  // namespace fos
+
 struct fos_comm {
   int nranks = 1, rank = 0;
+  int kind = 0;                               // 0: RCCL, 1: full-mesh one-shot kernel
   ncclComm_t nccl = nullptr;
   const fos::RcclApi* api = nullptr;
+  // mesh transport
+  char* inbox = nullptr;                      // local [2][nranks][cap_bytes]
+  unsigned long long* flags = nullptr;        // local [2][nranks][MESH_MAXWG]
+  int* err = nullptr;                         // device flag raised by a timed-out wait
+  size_t cap_bytes = 0;
+  unsigned long long seq = 0;
+  fos::MeshPeers peers{};
+  void* opened[2 * fos::MESH_MAXRANKS] = {};  // IPC mappings to close
+  int n_opened = 0;
 };

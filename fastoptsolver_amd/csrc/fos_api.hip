@@ -17,6 +17,7 @@
 #include "gemv_pair.hpp"
 #include "gemv_tall.hpp"
 #include "gemv_wide.hpp"
+#include "gram_batch.hpp"
 #include "lbfgs_kernels.hpp"
 #include "reduce_update.hpp"
 #include "resident.hpp"
@@ -294,6 +295,12 @@ struct fos_problem {
   double* q_part = nullptr;
   double* bt_out = nullptr;          // 128 doubles
   int64_t n_pad = 0;
+  // multi-lambda pass on the matrix cores (gram_batch.hpp): residual panel and the 16 gradient slab sets
+  float* rbuf16 = nullptr;           // panel_rows x 16 floats
+  float* slabs16 = nullptr;          // splits x 16 x n floats
+  int64_t panel_rows = 0;
+  int gram_splits = 0;
+  int64_t gram_rows_per_split = 0;
   // optional kernel timing (fos_problem_profile)
   int profiling = 0;                 // 0 off, N: bracket every N-th launch of the A pass
   int64_t prof_seq = 0;
@@ -467,12 +474,34 @@ int launch_pass_inner(fos_problem* p, const YSource& ys, const float* b, bool wi
   return FOS_OK;
 }
 
+// In-place sum over the ranks of a communicator on `st`: RCCL, or the one-shot full-mesh kernel (comm.hpp).
+int comm_allreduce(fos_comm* c, void* buf, size_t count, bool f64, hipStream_t st) {
+  if (c->kind == 0) {
+    const ncclResult_t r = c->api->AllReduce(buf, buf, count, f64 ? ncclDouble : ncclFloat, ncclSum, c->nccl, st);
+    if (r != ncclSuccess) return fail(FOS_ERR_HIP, std::string("ncclAllReduce: ") + c->api->GetErrorString(r));
+    return FOS_OK;
+  }
+  const size_t esz = f64 ? 8 : 4;
+  if (count * esz > c->cap_bytes)
+    return fail(FOS_ERR_ARG, "mesh all-reduce: message larger than the inbox rows the communicator was created with");
+  if (count == 0) return FOS_OK;
+  c->seq += 1;
+  const int nwg = (int)std::max<size_t>(1, std::min<size_t>(fos::MESH_MAXWG, (count * esz + 4095) / 4096));
+  const unsigned long long timeout = 100000000ull * 20ull;      // 20 s of the 100 MHz wall clock
+  if (f64)
+    hipLaunchKernelGGL(fos::mesh_allreduce_kernel<double>, dim3(nwg), dim3(fos::MESH_THREADS), 0, st, c->peers, c->nranks,
+                       c->rank, (double*)buf, (long long)count, c->seq, (long long)(c->cap_bytes / 8), timeout, c->err);
+  else
+    hipLaunchKernelGGL(fos::mesh_allreduce_kernel<float>, dim3(nwg), dim3(fos::MESH_THREADS), 0, st, c->peers, c->nranks,
+                       c->rank, (float*)buf, (long long)count, c->seq, (long long)(c->cap_bytes / 4), timeout, c->err);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
 // Sum `count` floats / doubles over the ranks of a sharded problem, in place, on the handle's stream (no-op otherwise).
 int reduce_across(fos_problem* p, void* buf, size_t count, bool f64) {
   if (!p->comm) return FOS_OK;
-  const ncclResult_t r = p->comm->api->AllReduce(buf, buf, count, f64 ? ncclDouble : ncclFloat, ncclSum, p->comm->nccl, p->stream);
-  if (r != ncclSuccess) return fail(FOS_ERR_HIP, std::string("ncclAllReduce: ") + p->comm->api->GetErrorString(r));
-  return FOS_OK;
+  return comm_allreduce(p->comm, buf, count, f64, p->stream);
 }
 
 __global__ void rr_from_gbuf_kernel(const float* __restrict__ gbuf, int n, double* __restrict__ rr_out, const int* stopped) {
@@ -526,42 +555,52 @@ int ensure_batch_workspace(fos_problem* p) {
 // Measured at 65536 x 8192 (tools/bench_bq.py): <1,128> 208.6 us, <2,64> 213.5 us, <2,128> 166.6 us (80.6 % of HBM),
 // <4,64> 170.4 us.  The 128-row tile halves the LDS re-reads of the candidate fragments per byte of A; the 64-row
 // tile is kept for short problems, where it gives twice as many workgroups.
-typedef void (*Bf16Batch)(const fos::bf16_t*, int64_t, const float*, int, int64_t, int, const unsigned short*, int64_t, double*);
-struct Bf16BatchVariant { Bf16Batch fn; int rows; int wg_per_cu; };
+typedef void (*Bf16Batch)(const fos::bf16_t*, int64_t, const float*, int, int64_t, int, const unsigned short*, int64_t, double*,
+                          float*);
+struct Bf16BatchVariant { Bf16Batch fn, fn_store; int rows; int wg_per_cu; };     // fn_store: also keeps R (gram_batch.hpp)
 const Bf16BatchVariant kBf16Batch[] = {
-    {fos::residual_batch_mfma_bf16_kernel<1, 128>, 64, 2},
-    {fos::residual_batch_mfma_bf16_kernel<2, 128>, 128, 1},
+    {fos::residual_batch_mfma_bf16_kernel<1, 128>, fos::residual_batch_mfma_bf16_kernel<1, 128, true>, 64, 2},
+    {fos::residual_batch_mfma_bf16_kernel<2, 128>, fos::residual_batch_mfma_bf16_kernel<2, 128, true>, 128, 1},
 };
 
-typedef void (*F32Batch)(const float*, int64_t, const float*, int, int64_t, int, const float*, int64_t, double*);
-struct F32BatchVariant { F32Batch fn; int rows; int wg_per_cu; };
+typedef void (*F32Batch)(const float*, int64_t, const float*, int, int64_t, int, const float*, int64_t, double*, float*);
+struct F32BatchVariant { F32Batch fn, fn_store; int rows; int wg_per_cu; };
 // fp32, measured at 65536 x 8192: <1> 64-row tile 368-395 us, <2> 128-row tile 335.7 us (80 % of HBM), <4> 336.8 us.
 const F32BatchVariant kF32Batch[] = {
-    {fos::residual_batch_mfma_kernel<1>, 64, 3},
-    {fos::residual_batch_mfma_kernel<2>, 128, 2},
+    {fos::residual_batch_mfma_kernel<1>, fos::residual_batch_mfma_kernel<1, true>, 64, 3},
+    {fos::residual_batch_mfma_kernel<2>, fos::residual_batch_mfma_kernel<2, true>, 128, 2},
 };
 
-// q[j] = ||A Xp_j - use_b*b||^2 -> out16 (device); Xp already in p->xp.
-int launch_residual_batch(fos_problem* p, int use_b, double* out16) {
+// Product 1 on `rows` rows starting at A / b: q_part[wg][16] partial squared norms, rout (nullable): the residuals.
+// Returns the number of workgroups (rows of q_part).
+int launch_batch_product(fos_problem* p, const void* A, const float* b, int64_t rows_total, int use_b, float* rout, int* nwg_out) {
   const bool is_bf16 = p->dtype == FOS_BF16;
-  const int variant = p->m >= 128 * (int64_t)p->ncu ? 1 : 0;
-  const int fv = variant;
-  const int rows = is_bf16 ? kBf16Batch[variant].rows : kF32Batch[fv].rows;
-  const int per_cu = is_bf16 ? kBf16Batch[variant].wg_per_cu : kF32Batch[fv].wg_per_cu;
-  const int64_t ngroups = (p->m + rows - 1) / rows;
+  const int variant = rows_total >= 128 * (int64_t)p->ncu ? 1 : 0;
+  const int rows = is_bf16 ? kBf16Batch[variant].rows : kF32Batch[variant].rows;
+  const int per_cu = is_bf16 ? kBf16Batch[variant].wg_per_cu : kF32Batch[variant].wg_per_cu;
+  const int64_t ngroups = (rows_total + rows - 1) / rows;
   int64_t nwg = std::min<int64_t>(ngroups, per_cu * (int64_t)p->ncu);
   const int64_t gpw = (ngroups + nwg - 1) / nwg;
   nwg = (ngroups + gpw - 1) / gpw;
+  if (is_bf16)
+    hipLaunchKernelGGL(rout ? kBf16Batch[variant].fn_store : kBf16Batch[variant].fn, dim3((unsigned)nwg),
+                       dim3(fos::BT_THREADS), 0, p->stream, (const fos::bf16_t*)A, p->lda, b, (use_b && b) ? 1 : 0,
+                       rows_total, (int)p->n, (const unsigned short*)p->xp, gpw, p->q_part, rout);
+  else
+    hipLaunchKernelGGL(rout ? kF32Batch[variant].fn_store : kF32Batch[variant].fn, dim3((unsigned)nwg),
+                       dim3(fos::BT_THREADS), 0, p->stream, (const float*)A, p->lda, b, (use_b && b) ? 1 : 0, rows_total,
+                       (int)p->n, p->xp, gpw, p->q_part, rout);
+  LAUNCH_CHECK();
+  *nwg_out = (int)nwg;
+  return FOS_OK;
+}
+
+// q[j] = ||A Xp_j - use_b*b||^2 -> out16 (device); Xp already in p->xp.
+int launch_residual_batch(fos_problem* p, int use_b, double* out16) {
   int rc = prof_mark(p, true);
   if (rc) return rc;
-  if (is_bf16)
-    hipLaunchKernelGGL(kBf16Batch[variant].fn, dim3((unsigned)nwg), dim3(fos::BT_THREADS), 0, p->stream,
-                       (const fos::bf16_t*)p->A, p->lda, p->b, (use_b && p->b) ? 1 : 0, p->m, (int)p->n,
-                       (const unsigned short*)p->xp, gpw, p->q_part);
-  else
-    hipLaunchKernelGGL(kF32Batch[fv].fn, dim3((unsigned)nwg), dim3(fos::BT_THREADS), 0, p->stream,
-                       (const float*)p->A, p->lda, p->b, (use_b && p->b) ? 1 : 0, p->m, (int)p->n, p->xp, gpw, p->q_part);
-  LAUNCH_CHECK();
+  int nwg = 0;
+  if ((rc = launch_batch_product(p, p->A, p->b, p->m, use_b, nullptr, &nwg))) return rc;
   if ((rc = prof_mark(p, false))) return rc;
   hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->q_part, (int)nwg, fos::BT_NV, out16);
   LAUNCH_CHECK();
@@ -732,7 +771,71 @@ int fos_comm_create(fos_comm** out, const char id[128], int nranks, int rank) {
 int fos_comm_destroy(fos_comm* c) {
   if (!c) return FOS_OK;
   if (c->nccl) (void)c->api->CommDestroy(c->nccl);
+  for (int i = 0; i < c->n_opened; ++i) (void)hipIpcCloseMemHandle(c->opened[i]);
+  void* bufs[] = {c->inbox, c->flags, c->err};
+  for (void* q : bufs)
+    if (q) (void)hipFree(q);
   delete c;
+  return FOS_OK;
+}
+
+// ---- full-mesh transport: local allocation + IPC handles, then the peers' handles -----------------------------------
+int fos_comm_mesh_create(fos_comm** out, int nranks, int rank, int64_t cap_bytes, char handles[128]) {
+  if (!out || !handles || nranks < 1 || nranks > fos::MESH_MAXRANKS || rank < 0 || rank >= nranks || cap_bytes < 16)
+    return fail(FOS_ERR_ARG, "fos_comm_mesh_create: bad argument (1..8 ranks)");
+  fos_comm* c = new fos_comm();
+  c->kind = 1; c->nranks = nranks; c->rank = rank;
+  c->cap_bytes = ((size_t)cap_bytes + 63) & ~(size_t)63;
+  const size_t inbox_bytes = 2 * (size_t)nranks * c->cap_bytes;
+  const size_t flag_bytes = 2 * (size_t)nranks * fos::MESH_MAXWG * sizeof(unsigned long long);
+  hipError_t e = hipMalloc(&c->inbox, inbox_bytes);
+  if (e == hipSuccess) e = hipMalloc(&c->flags, flag_bytes);
+  if (e == hipSuccess) e = hipMalloc(&c->err, sizeof(int));
+  if (e == hipSuccess) e = hipMemset(c->inbox, 0, inbox_bytes);
+  if (e == hipSuccess) e = hipMemset(c->flags, 0, flag_bytes);
+  if (e == hipSuccess) e = hipMemset(c->err, 0, sizeof(int));
+  hipIpcMemHandle_t h0, h1;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "two IPC handles travel in 128 bytes");
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&h0, c->inbox);
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&h1, c->flags);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    fos_comm_destroy(c);
+    return fail(FOS_ERR_HIP, std::string("fos_comm_mesh_create: ") + hipGetErrorString(e));
+  }
+  std::memcpy(handles, &h0, 64);
+  std::memcpy(handles + 64, &h1, 64);
+  c->peers.inbox[rank] = c->inbox;
+  c->peers.flags[rank] = c->flags;
+  *out = c;
+  return FOS_OK;
+}
+
+int fos_comm_mesh_connect(fos_comm* c, const char* all_handles) {
+  if (!c || c->kind != 1 || !all_handles) return fail(FOS_ERR_ARG, "fos_comm_mesh_connect: bad argument");
+  for (int p = 0; p < c->nranks; ++p) {
+    if (p == c->rank) continue;
+    hipIpcMemHandle_t h0, h1;
+    std::memcpy(&h0, all_handles + (size_t)p * 128, 64);
+    std::memcpy(&h1, all_handles + (size_t)p * 128 + 64, 64);
+    void *a = nullptr, *b = nullptr;
+    HIP_TRY(hipIpcOpenMemHandle(&a, h0, hipIpcMemLazyEnablePeerAccess));
+    c->opened[c->n_opened++] = a;
+    HIP_TRY(hipIpcOpenMemHandle(&b, h1, hipIpcMemLazyEnablePeerAccess));
+    c->opened[c->n_opened++] = b;
+    c->peers.inbox[p] = (char*)a;
+    c->peers.flags[p] = (unsigned long long*)b;
+  }
+  return FOS_OK;
+}
+
+int fos_comm_check(fos_comm* c, void* stream) {
+  if (!c) return fail(FOS_ERR_ARG, "fos_comm_check: null");
+  if (c->kind != 1) return FOS_OK;
+  int bad = 0;
+  HIP_TRY(hipMemcpyAsync(&bad, c->err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  if (bad) return fail(FOS_ERR_STATE, "mesh all-reduce: a peer did not deliver within the time limit; results are invalid");
   return FOS_OK;
 }
 
@@ -753,10 +856,7 @@ const char* fos_comm_transport(void) {
 
 int fos_comm_allreduce(fos_comm* c, void* buf, int64_t count, int is_f64, void* stream) {
   if (!c || !buf || count < 0) return fail(FOS_ERR_ARG, "fos_comm_allreduce: bad argument");
-  const ncclResult_t r = c->api->AllReduce(buf, buf, (size_t)count, is_f64 ? ncclDouble : ncclFloat, ncclSum, c->nccl,
-                                           (hipStream_t)stream);
-  if (r != ncclSuccess) return fail(FOS_ERR_HIP, std::string("ncclAllReduce: ") + c->api->GetErrorString(r));
-  return FOS_OK;
+  return comm_allreduce(c, buf, (size_t)count, is_f64 != 0, (hipStream_t)stream);
 }
 
 int fos_problem_set_comm(fos_problem* p, fos_comm* c) {
@@ -820,7 +920,7 @@ int fos_problem_destroy(fos_problem* p) {
   if (!p) return FOS_OK;
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   void* bufs[] = {p->slabs, p->rr_part, p->rr2_part, p->rvec, p->gbuf_own, p->ybuf, p->dscal, p->part, p->xp, p->q_part, p->bt_out,
-                  p->slabs_dd, p->rr_dd, p->lhist};
+                  p->slabs_dd, p->rr_dd, p->lhist, p->rbuf16, p->slabs16};
   for (void* q : bufs)
     if (q) (void)hipFree(q);
   delete p;
@@ -1195,18 +1295,20 @@ static void host_momentum(const fos::FistaParams& prm, long long k, double* t, d
 
 static void launch_update_from_slabs(fos_fista* f, double* part, int host_beta, double beta_val,
                                      double* x_hist = nullptr, float* y_next = nullptr, double beta_next = 0.0,
-                                     const float* slabs = nullptr, int64_t slab_stride = 0) {
+                                     const float* slabs = nullptr, int64_t slab_stride = 0, int nslabs = 0,
+                                     int y_mode = fos::YOUT_VECTOR, int y_slot = 0) {
   fos_problem* p = f->p;
   if (slabs == nullptr) slabs = p->slabs;
   if (slab_stride == 0) slab_stride = p->slab_stride;
+  if (nslabs == 0) nslabs = p->nslabs;
   if (p->vec4)
     hipLaunchKernelGGL((fos::fista_update_kernel<true, true>), dim3(f->nupd), dim3(256), 0, p->stream, slabs,
-                       p->nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
-                       beta_val, x_hist, y_next, beta_next, slab_stride);
+                       nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
+                       beta_val, x_hist, y_next, beta_next, slab_stride, y_mode, y_slot);
   else
     hipLaunchKernelGGL((fos::fista_update_kernel<true, false>), dim3(f->nupd), dim3(256), 0, p->stream, slabs,
-                       p->nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
-                       beta_val, x_hist, y_next, beta_next, slab_stride);
+                       nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
+                       beta_val, x_hist, y_next, beta_next, slab_stride, y_mode, y_slot);
 }
 
 // y source of a plain-run iteration: the fp32 vector the previous update kernel wrote, or (first iteration after a
@@ -1435,15 +1537,128 @@ int fos_fista_run(fos_fista* f, int iters) {
   return FOS_OK;
 }
 
+// Up to 16 state machines in lockstep on the matrix cores (gram_batch.hpp): per iteration and per row panel, product 1
+// (R = A_panel Y - b, from HBM) and product 2 (G += R^T A_panel, the panel again from the Infinity Cache), then one
+// update kernel per state machine, which leaves its y_{k+1} in the candidate block of the next product 1.
+static int run_multi_mfma(fos_fista* const* fs, int nv, int iters) {
+  fos_problem* p = fs[0]->p;
+  int rc = ensure_batch_workspace(p);
+  if (rc) return rc;
+  const bool is_bf16 = p->dtype == FOS_BF16;
+  const int64_t esz = is_bf16 ? 2 : 4;
+  if (!p->rbuf16) {
+    // Panel: product 1 gives a workgroup 64-128 whole rows, so it needs >= 128 * CUs * 2 rows to fill the chip; row
+    // splits of product 2: enough (strip, split) workgroups for two per CU.  (A panel that fits the Infinity Cache
+    // - ~3000 rows at n = 8192 - would need a split-K product 1; see DESIGN.md "Multi-lambda".)
+    const int64_t rows = 256 * (int64_t)p->ncu;
+    p->panel_rows = std::min<int64_t>(rows, (p->m + 255) / 256 * 256);
+    const int64_t strips = (p->n + fos::GB_COLS - 1) / fos::GB_COLS;
+    int64_t splits = std::max<int64_t>(1, (2 * (int64_t)p->ncu + strips - 1) / strips);
+    splits = std::min<int64_t>(splits, std::max<int64_t>(1, p->panel_rows / 256));
+    p->gram_rows_per_split = ((p->panel_rows + splits - 1) / splits + fos::GB_ROWS - 1) / fos::GB_ROWS * fos::GB_ROWS;
+    p->gram_splits = (int)((p->panel_rows + p->gram_rows_per_split - 1) / p->gram_rows_per_split);
+    HIP_TRY(hipMalloc(&p->rbuf16, (size_t)p->panel_rows * fos::BT_NV * sizeof(float)));
+    HIP_TRY(hipMalloc(&p->slabs16, (size_t)p->gram_splits * fos::BT_NV * p->n * sizeof(float)));
+  }
+  // candidate block: zero everywhere (padding columns, unused slots), then y_k of every state machine
+  const size_t per_entry = is_bf16 ? 3 * sizeof(unsigned short) : sizeof(float);
+  HIP_TRY(hipMemsetAsync(p->xp, 0, (size_t)p->n_pad * fos::BT_NV * per_entry, p->stream));
+  for (int v = 0; v < nv; ++v) {
+    fos_fista* f = fs[v];
+    if ((rc = flush_pending(f))) return rc;
+    bool stopped = false;
+    if ((rc = refresh_host_scalars(f, &stopped))) return rc;
+    if (stopped) return fail(FOS_ERR_STATE, "fos_fista_run_multi: a handle has already stopped");
+    hipLaunchKernelGGL(fos::form_y_block_kernel, dim3(grid_1d(p->n, 256, 256)), dim3(256), 0, p->stream, f->x_cur, f->x_prev,
+                       f->h_beta, (int)p->n, v, is_bf16 ? (float*)nullptr : p->xp,
+                       is_bf16 ? (unsigned short*)p->xp : (unsigned short*)nullptr);
+    LAUNCH_CHECK();
+    f->y_valid = false;              // the fp32 y vector of the single-vector path is not maintained here
+    f->plain_count = 0;
+  }
+  const size_t psz = (size_t)fs[0]->nupd * 4;
+  const int64_t strips = (p->n + fos::GB_COLS - 1) / fos::GB_COLS;
+  // one update launch for all state machines when they differ in weights and steps only (a regularisation path does)
+  bool same_family = true;
+  for (int v = 1; v < nv; ++v) {
+    const fos::FistaParams &a = fs[0]->prm, &c = fs[v]->prm;
+    same_family = same_family && a.mode == c.mode && a.prox_kind == c.prox_kind && a.delta == c.delta;
+  }
+  for (int it = 0; it < iters; ++it) {
+    if ((rc = prof_mark(p, true))) return rc;
+    for (int64_t row0 = 0, panel = 0; row0 < p->m; row0 += p->panel_rows, ++panel) {
+      const int64_t rows = std::min<int64_t>(p->panel_rows, p->m - row0);
+      const char* Ap = reinterpret_cast<const char*>(p->A) + (size_t)row0 * p->lda * esz;
+      int nwg1 = 0;
+      if ((rc = launch_batch_product(p, Ap, p->b ? p->b + row0 : nullptr, rows, 1, p->rbuf16, &nwg1))) return rc;
+      const dim3 grid((unsigned)strips, (unsigned)p->gram_splits);
+#define FOS_GRAM(T, ACC)                                                                                                  \
+  hipLaunchKernelGGL((fos::gram_batch_mfma_kernel<T, ACC>), grid, dim3(fos::GB_THREADS), 0, p->stream, (const T*)Ap, p->lda, \
+                     rows, (int)p->n, p->rbuf16, p->gram_rows_per_split, p->slabs16, p->n)
+      if (is_bf16) { if (panel) FOS_GRAM(fos::bf16_t, true); else FOS_GRAM(fos::bf16_t, false); }
+      else { if (panel) FOS_GRAM(float, true); else FOS_GRAM(float, false); }
+#undef FOS_GRAM
+      LAUNCH_CHECK();
+    }
+    if ((rc = prof_mark(p, false))) return rc;
+    if (same_family) {                           // one launch updates all state machines
+      fos::MultiUpdate mu{};
+      for (int v = 0; v < nv; ++v) {
+        fos_fista* f = fs[v];
+        mu.x_cur[v] = f->x_cur; mu.x_prev[v] = f->x_prev; mu.scal[v] = f->scal;
+        mu.part[v] = f->part2 + (size_t)(f->h_k & 1) * psz;
+        mu.beta[v] = f->h_beta;
+        host_momentum(f->prm, f->h_k, &f->h_t, &f->h_beta);
+        mu.beta_next[v] = f->h_beta;
+        mu.alpha1[v] = f->prm.alpha1; mu.alpha2[v] = f->prm.alpha2; mu.tau[v] = f->prm.tau;
+        f->h_k += 1;
+        f->plain_count += 1;
+      }
+      hipLaunchKernelGGL(fos::fista_update_multi_kernel, dim3(fs[0]->nupd, nv), dim3(256), 0, p->stream, p->slabs16,
+                         p->gram_splits, (int)p->n, mu, fs[0]->prm, p->xp, is_bf16 ? fos::YOUT_XQ : fos::YOUT_XP);
+      LAUNCH_CHECK();
+    } else {
+      for (int v = 0; v < nv; ++v) {
+        fos_fista* f = fs[v];
+        const double beta_k = f->h_beta;
+        host_momentum(f->prm, f->h_k, &f->h_t, &f->h_beta);
+        launch_update_from_slabs(f, f->part2 + (size_t)(f->h_k & 1) * psz, 1, beta_k, nullptr, p->xp, f->h_beta,
+                                 p->slabs16 + (size_t)v * p->n, (int64_t)fos::BT_NV * p->n, p->gram_splits,
+                                 is_bf16 ? fos::YOUT_XQ : fos::YOUT_XP, v);
+        LAUNCH_CHECK();
+        f->h_k += 1;
+        f->plain_count += 1;
+      }
+    }
+  }
+  for (int v = 0; v < nv; ++v) {
+    fos_fista* f = fs[v];
+    f->pending = false;
+    const long long last = f->h_k - 1;
+    const double* cur = f->part2 + (size_t)(last & 1) * psz;
+    const double* prev = f->plain_count >= 2 ? f->part2 + (size_t)((last - 1) & 1) * psz : nullptr;
+    hipLaunchKernelGGL(fos::fista_finalize_plain_kernel, dim3(1), dim3(64), 0, p->stream, cur, prev, f->nupd, p->rr_part, 0,
+                       f->scal, f->h_t, f->h_beta, f->h_k);
+    LAUNCH_CHECK();
+    f->plain_count = 0;              // part2 of the next single-vector run starts afresh
+  }
+  return FOS_OK;
+}
+
 int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters) {
-  if (!fs || nv < 1 || nv > 4 || iters < 0) return fail(FOS_ERR_ARG, "fos_fista_run_multi: bad argument");
+  if (!fs || nv < 1 || nv > fos::BT_NV || iters < 0) return fail(FOS_ERR_ARG, "fos_fista_run_multi: bad argument");
   for (int v = 0; v < nv; ++v)
     if (!fs[v] || fs[v]->p != fs[0]->p) return fail(FOS_ERR_ARG, "fos_fista_run_multi: handles must share one problem");
   if (nv == 1) return fos_fista_run(fs[0], iters);
   fos_problem* p = fs[0]->p;
-  MultiLaunch fn = (p->path == 0 && !p->tall && p->dtype == FOS_F32 && !p->comm) ? find_multi(p->n, nv) : nullptr;
-  for (int v = 0; v < nv && fn; ++v)
-    if (!plain_run(fs[v])) fn = nullptr;
+  bool all_plain = true;
+  for (int v = 0; v < nv; ++v) all_plain = all_plain && plain_run(fs[v]);
+  const bool streaming = p->path == 0 && !p->tall && !p->comm && !p->resident && all_plain;
+  MultiLaunch fn = (streaming && p->dtype == FOS_F32 && p->entry != &kWideF32) ? find_multi(p->n, nv) : nullptr;
+  if (!fn && streaming && p->entry != &kWideF32) {
+    if (iters == 0) return FOS_OK;
+    return run_multi_mfma(fs, nv, iters);          // 5..16 weights, n up to 16384, fp32 and bf16
+  }
   if (!fn) return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_multi: no multi-vector kernel for this shape / configuration");
   if (iters == 0) return FOS_OK;
   // workspace: nv interleaved slab sets and rr partials per workgroup

@@ -53,6 +53,28 @@ struct FistaParams {
   int pad;
 };
 
+// ---- candidate / multi-lambda block layouts of the matrix-core kernels (batch_trial.hpp, gram_batch.hpp) -----------
+constexpr int BT_NV = 16;            // right-hand sides per pass (MFMA N)
+// X block layout ("Xp"): for column k and candidate j,
+//   Xp[ ((k/16)*4 + (k%16)/4) * 64 + j*4 + (k%4) ]
+// i.e. per 16-column subtile a [q = 4][j = 16][c = 4] cube: the float4 a lane needs for one subtile is contiguous and
+// the 64 lanes of a wave read 1 KiB contiguous.
+__device__ __host__ inline int64_t xp_index(int64_t k, int j) {
+  return ((k / 16) * 4 + (k % 16) / 4) * 64 + (int64_t)j * 4 + (k % 4);
+}
+// bf16 A: candidate block "Xq", three bf16 terms per value (see batch_trial.hpp):
+//   Xq[ (((k/32)*3 + p)*4 + (k%32)/8) * 128 + j*8 + (k%8) ]
+__device__ __host__ inline int64_t xq_index(int64_t k, int j, int part) {
+  return (((k / 32) * 3 + part) * 4 + (k % 32) / 8) * 128 + (int64_t)j * 8 + (k % 8);
+}
+__device__ inline unsigned short f32_to_bf16_rn(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);      // finite inputs only (differences of iterates)
+}
+__device__ inline float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+// where the update kernel leaves y_{k+1} for the next pass over A
+enum : int { YOUT_VECTOR = 0, YOUT_XP = 1, YOUT_XQ = 2 };
+
 __device__ inline double soft_threshold(double v, double thr) {
   double mag = fabs(v) - thr;
   mag = (mag < 0.0) ? 0.0 : mag;
@@ -220,14 +242,14 @@ __global__ __launch_bounds__(256) void slab_reduce_dd_kernel(const double* __res
 // per-workgroup partial sums  part[wg] = {sum d^2, sum g_full^2, sum |x_next|, sum x_next^2}.
 // ---------------------------------------------------------------------------------------------------------
 template <bool FROM_SLABS, bool VEC>
-__global__ __launch_bounds__(256) void fista_update_kernel(const float* __restrict__ slabs, int nslabs,
+__device__ inline void fista_update_body(const float* __restrict__ slabs, int nslabs,
                                                           const float* __restrict__ gbuf, int n,
                                                           double* __restrict__ x_cur, double* __restrict__ x_prev,
                                                           const FistaScalars* __restrict__ scal, FistaParams prm,
                                                           double* __restrict__ part, int host_beta, double beta_val,
-                                                          double* __restrict__ x_hist = nullptr,
-                                                          float* __restrict__ y_next = nullptr, double beta_next = 0.0,
-                                                          int64_t slab_stride = 0) {
+                                                          double* __restrict__ x_hist,
+                                                          float* __restrict__ y_next, double beta_next,
+                                                          int64_t slab_stride, int y_mode, int y_slot) {
   if (scal->stopped != 0) return;
   __shared__ f32x4 lds[RG][RQ];
   __shared__ double dl[4 * 4];
@@ -274,13 +296,63 @@ __global__ __launch_bounds__(256) void fista_update_kernel(const float* __restri
     x_cur[col + e] = xn;
     if (x_hist != nullptr) x_hist[col + e] = xn;      // device-resident history (fos_fista_run_history)
     // plain runs: beta_{k+1} is known, hand the next A pass its y as ONE fp32 vector (same form_y, same rounding)
-    if (y_next != nullptr) y_next[col + e] = (float)form_y(xn, xc, beta_next);
+    if (y_next != nullptr) {
+      const float yn = (float)form_y(xn, xc, beta_next);
+      if (y_mode == YOUT_VECTOR) {
+        y_next[col + e] = yn;
+      } else if (y_mode == YOUT_XP) {                  // slot of the multi-lambda block (gram_batch.hpp)
+        y_next[xp_index(col + e, y_slot)] = yn;
+      } else {                                         // bf16 A: three bf16 terms
+        unsigned short* xq = reinterpret_cast<unsigned short*>(y_next);
+        const unsigned short hi = f32_to_bf16_rn(yn);
+        const float r1 = yn - bf16_to_f32(hi);
+        const unsigned short mid = f32_to_bf16_rn(r1);
+        xq[xq_index(col + e, y_slot, 0)] = hi;
+        xq[xq_index(col + e, y_slot, 1)] = mid;
+        xq[xq_index(col + e, y_slot, 2)] = f32_to_bf16_rn(r1 - bf16_to_f32(mid));
+      }
+    }
   }
   block_sum_256<4>(acc, dl);
   if (threadIdx.x == 0) {
     part[blockIdx.x * 4 + 0] = acc[0]; part[blockIdx.x * 4 + 1] = acc[1];
     part[blockIdx.x * 4 + 2] = acc[2]; part[blockIdx.x * 4 + 3] = acc[3];
   }
+}
+
+
+template <bool FROM_SLABS, bool VEC>
+__global__ __launch_bounds__(256) void fista_update_kernel(const float* __restrict__ slabs, int nslabs,
+                                                          const float* __restrict__ gbuf, int n,
+                                                          double* __restrict__ x_cur, double* __restrict__ x_prev,
+                                                          const FistaScalars* __restrict__ scal, FistaParams prm,
+                                                          double* __restrict__ part, int host_beta, double beta_val,
+                                                          double* __restrict__ x_hist = nullptr,
+                                                          float* __restrict__ y_next = nullptr, double beta_next = 0.0,
+                                                          int64_t slab_stride = 0, int y_mode = YOUT_VECTOR,
+                                                          int y_slot = 0) {
+  fista_update_body<FROM_SLABS, VEC>(slabs, nslabs, gbuf, n, x_cur, x_prev, scal, prm, part, host_beta, beta_val, x_hist,
+                                     y_next, beta_next, slab_stride, y_mode, y_slot);
+}
+
+// The updates of up to 16 lockstep state machines in ONE launch (multi-lambda pass, gram_batch.hpp): blockIdx.y selects
+// the state machine; its slab set is slabs + y*n with slab stride 16*n, its y_{k+1} goes to slot y of the block.
+struct MultiUpdate {
+  double* x_cur[BT_NV];
+  double* x_prev[BT_NV];
+  const FistaScalars* scal[BT_NV];
+  double* part[BT_NV];
+  double beta[BT_NV], beta_next[BT_NV];
+  double alpha1[BT_NV], alpha2[BT_NV], tau[BT_NV];
+};
+__global__ __launch_bounds__(256) void fista_update_multi_kernel(const float* __restrict__ slabs, int nslabs, int n,
+                                                                MultiUpdate mu, FistaParams prm0, float* __restrict__ y_block,
+                                                                int y_mode) {
+  const int v = blockIdx.y;
+  FistaParams prm = prm0;                       // mode / prox kind / delta are common to the path; weights and steps are not
+  prm.alpha1 = mu.alpha1[v]; prm.alpha2 = mu.alpha2[v]; prm.tau = mu.tau[v];
+  fista_update_body<true, true>(slabs + (int64_t)v * n, nslabs, nullptr, n, mu.x_cur[v], mu.x_prev[v], mu.scal[v], prm,
+                                mu.part[v], 1, mu.beta[v], nullptr, y_block, mu.beta_next[v], (int64_t)BT_NV * n, y_mode, v);
 }
 
 // One wave: fold the partials and advance the scalar state.  iterative_solvers.py:204-221, :235-242, :325-342.

@@ -37,13 +37,33 @@ class Comm:
     id from rank 0 to the others); the current device must be this rank's GPU.  ``Comm.solo()`` is a one-rank
     communicator that needs no process group (the all-reduce path on a single GPU: tests, rehearsals)."""
 
-    def __init__(self, group=None, _solo=False):
+    def __init__(self, group=None, _solo=False, transport="rccl", cap_bytes=1 << 18):
+        """transport "rccl" (default) or "mesh": the one-shot full-mesh kernel (fos_comm_mesh_*: every rank writes its
+        vector into an IPC-mapped inbox on every peer and sums the rows in rank order - one launch, one link latency,
+        for messages up to cap_bytes; needs all ranks on one node, at most 8)."""
         self.lib = _lib.load()
         _core.require_gpu()
         if _solo:
             world, rank = 1, 0
         else:
             world, rank = dist.get_world_size(group), dist.get_rank(group)
+        self.kind = transport
+        h = C.c_void_p()
+        if transport == "mesh":
+            mine = C.create_string_buffer(128)
+            _lib.check(self.lib.fos_comm_mesh_create(C.byref(h), world, rank, int(cap_bytes), mine), "fos_comm_mesh_create")
+            handles = [None] * world
+            if world > 1:
+                dist.all_gather_object(handles, mine.raw, group=group)
+            else:
+                handles[0] = mine.raw
+            _lib.check(self.lib.fos_comm_mesh_connect(h, b"".join(handles)), "fos_comm_mesh_connect")
+            if world > 1:
+                dist.barrier(group=group)            # every inbox is mapped everywhere before the first push
+            self.h, self.world, self.rank = h, world, rank
+            return
+        if transport != "rccl":
+            raise ValueError("transport must be 'rccl' or 'mesh'")
         ids = [None]
         if rank == 0:
             buf = C.create_string_buffer(128)
@@ -52,16 +72,20 @@ class Comm:
         if world > 1:
             src = dist.get_global_rank(group, 0) if group is not None else 0
             dist.broadcast_object_list(ids, src=src, group=group)
-        h = C.c_void_p()
         _lib.check(self.lib.fos_comm_create(C.byref(h), ids[0], world, rank), "fos_comm_create")
         self.h, self.world, self.rank = h, world, rank
 
     @classmethod
-    def solo(cls):
-        return cls(_solo=True)
+    def solo(cls, transport="rccl"):
+        return cls(_solo=True, transport=transport)
 
     def transport(self):
-        return self.lib.fos_comm_transport().decode()
+        return "mesh: one-shot full-mesh kernel over IPC-mapped inboxes" if self.kind == "mesh" else \
+            self.lib.fos_comm_transport().decode()
+
+    def check(self):
+        """Raise if a mesh all-reduce timed out waiting for a peer (synchronises); no-op for RCCL."""
+        _lib.check(self.lib.fos_comm_check(self.h, _core.stream_ptr()), "fos_comm_check")
 
     def allreduce(self, t):
         """In-place sum of a float32 / float64 device tensor over the ranks, on the current stream."""

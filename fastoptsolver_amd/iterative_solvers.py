@@ -514,9 +514,10 @@ def fista_path(A, b, alphas, t_init_factor: float = 1.0, max_iter: int = 500, *,
 
     ``alphas`` is a sequence of ``(alpha1, alpha2)`` pairs.  The result is the list of solutions that
     ``fista(A, b, ..., alpha1, alpha2, t_init_factor=t_init_factor, max_iter=max_iter, L=L)`` (or ``fista_delta``
-    when ``delta`` is given) would return one by one - same iterates - but up to four weights advance in lockstep and
-    every iteration reads A from HBM once for all of them (multi-vector form of the single-pass kernel; shapes
-    without such a kernel simply run one by one).  L is estimated once (one power iteration, one draw from the global
+    when ``delta`` is given) would return one by one - same iterates - but the weights advance in lockstep: up to four
+    share one read of A per iteration in the multi-vector form of the single-pass kernel (fp32, n <= 8192); five to
+    sixteen run on the matrix cores as two GEMM-shaped products per iteration for all of them (fp32 and bf16 storage,
+    any streaming shape: csrc/gram_batch.hpp).  Shapes without such a kernel simply run one by one.  L is estimated once (one power iteration, one draw from the global
     NumPy stream) unless given."""
     reset_metrics()
     if delta is not None:
@@ -531,8 +532,10 @@ def fista_path(A, b, alphas, t_init_factor: float = 1.0, max_iter: int = 500, *,
         st.reset(t_init_factor / (L_val + (a2 if a2 > 0 else 0.0)), a1, a2, mode=mode, delta=delta or 0.0)
         handles.append(st)
     gtimer = _EventTimer(grad_call_times)
-    for i in range(0, len(handles), 4):
-        group = handles[i:i + 4]
+    # up to 4 weights: the multi-vector VALU pass where the shape has one; up to 16: the matrix-core pass
+    width = 4 if len(handles) <= 4 else 16
+    for i in range(0, len(handles), width):
+        group = handles[i:i + width]
         ev = gtimer.start()
         if len(group) == 1 or not _core.run_multi(group, max_iter):
             for st in group:

@@ -104,12 +104,22 @@ int fos_problem_set_gbuf(fos_problem* p, float* gbuf);
  * floats per FISTA iteration (n + 1 doubles per L-BFGS fg), alpha2*y added after the reduction.  x_k, x_{k-1} and the
  * momentum scalars are replicated; every rank computes the identical update from identical numbers.  fos_fista_run
  * stays enqueue-only.  All ranks must issue the same calls in the same order.
- * Transport: RCCL over xGMI, resolved with dlopen at first use (fos_comm_transport() says which library).
+ * Transport: RCCL over xGMI, resolved with dlopen at first use (fos_comm_transport() says which library), or the
+ * one-shot full-mesh kernel below.
  *   fos_comm_unique_id   rank 0 creates the 128-byte id; the caller broadcasts it out of band (e.g. torch.distributed)
  *   fos_comm_create      collective over all ranks (ncclCommInitRank) on the CURRENT device
  *   fos_problem_set_comm attach (NULL detaches); the problem then never uses the one-workgroup resident loop. */
 int fos_comm_unique_id(char id[128]);
 int fos_comm_create(fos_comm** out, const char id[128], int nranks, int rank);
+/* Second transport: a one-shot all-reduce kernel over the full xGMI mesh - every rank writes its
+ * vector into an inbox on every peer (IPC-mapped device memory) and sums the P inbox rows in rank order: one launch, one
+ * link latency, results bit-identical on all ranks.  For the latency-bound n + 1 element exchange; messages up to
+ * cap_bytes.  fos_comm_mesh_create allocates this rank's inbox and returns 128 bytes of IPC handles; the caller gathers
+ * the handles of all ranks (rank order, 128 bytes each) and passes them to fos_comm_mesh_connect.  A peer that does not
+ * deliver within 20 s raises a device flag instead of hanging the kernel: fos_comm_check (synchronises) reports it. */
+int fos_comm_mesh_create(fos_comm** out, int nranks, int rank, int64_t cap_bytes, char handles[128]);
+int fos_comm_mesh_connect(fos_comm* c, const char* all_handles);
+int fos_comm_check(fos_comm* c, void* stream);
 int fos_comm_destroy(fos_comm* c);
 int fos_comm_info(const fos_comm* c, int* nranks, int* rank);
 const char* fos_comm_transport(void);
@@ -192,11 +202,14 @@ int fos_fista_run_resident(fos_fista* f, int iters, int backtracking, double eta
                            double* x_hist, double* hist, int32_t* ls_iters, double* tau_hist, int32_t* iters_done,
                            double* tau_out);
 int fos_fista_run_history(fos_fista* f, int iters, double* x_hist, double* hist, void* work);
-/* Regularisation path: nv <= 4 state machines bound to the SAME fos_problem (different alpha1 / alpha2 / tau) advance
- * `iters` plain iterations in lockstep; every iteration reads A from HBM once for all of them (multi-vector form of
- * the single-pass kernel).  Results are identical to running each handle with fos_fista_run.  FOS_ERR_UNSUPPORTED when
- * the shape has no multi-vector kernel (n > 8192, bf16, two-pass path) or a handle needs data-dependent control: the
- * caller then runs the handles one by one.  SURVEY.md 8(f) rank 3. */
+/* Regularisation path: nv <= 16 state machines bound to the SAME fos_problem (different alpha1 / alpha2 / tau) advance
+ * `iters` plain iterations in lockstep.  nv <= 4, fp32, n <= 8192: the multi-vector form of the single-pass kernel, A read
+ * from HBM once per iteration for all of them.  Otherwise (up to 16 weights, fp32 and bf16 storage, any streaming shape):
+ * two GEMM-shaped products per iteration on the matrix cores for all weights together, R = A Y - b (v_mfma_f32_16x16x4_f32
+ * / v_mfma_f32_16x16x32_bf16) and G = A^T R (csrc/gram_batch.hpp).  Results equal running each handle with
+ * fos_fista_run (1e-6).  FOS_ERR_UNSUPPORTED when the shape has no such kernel (two-pass path, n <= 64, n > 16384 fp32,
+ * sharded problems) or a handle needs data-dependent control: the caller then runs the handles one by one.
+ * SURVEY.md 8(f) rank 3. */
 int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters);
 /* Split form for host-driven control (grad-norm stop :179, backtracking :183-197, sharded runs):
  *   fos_fista_grad    gbuf[0..n) = A^T (A y_k - b) (WITHOUT alpha2*y), gbuf[n] = ||A y_k - b||^2 (float)

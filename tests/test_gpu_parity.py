@@ -863,6 +863,40 @@ def test_fista_path_equals_one_by_one(fos, nlam):
     assert _data.rel(xd[1], orc.fista_delta(A, b, "elasticnet", alphas[1][0], alphas[1][1], 3.0, max_iter=30, L=L)) < TOL
 
 
+@pytest.mark.parametrize("kind,m,n,nlam", [("f32", 4096, 512, 16), ("f32", 1000, 200, 7), ("f32", 333, 16384, 16),
+                                           ("bf16", 2000, 1024, 16), ("bf16", 700, 264, 5), ("f32", 70000, 128, 9)])
+def test_fista_path_sixteen_weights_on_the_matrix_cores(fos, kind, m, n, nlam):
+    """5..16 weights in lockstep: two GEMM-shaped products per iteration on MFMA (R = A Y - b, G = A^T R) for all of
+    them.  Equal to one-by-one runs (1e-6: same arithmetic, other summation order) and to the oracle (1e-5) - on the
+    bf16-ROUNDED A for bf16 storage; FISTA and FISTA-delta; ragged row counts, partial tiles, several panels."""
+    A, b, _ = _data.synth(m, n, 77 + n)
+    if kind == "bf16":
+        At = torch.as_tensor(A.astype(np.float32)).to(torch.bfloat16).cuda()
+        A = At.to(torch.float64).cpu().numpy()
+    else:
+        At = torch.as_tensor(A.astype(np.float32)).cuda()
+        A = At.to(torch.float64).cpu().numpy()
+    b = b.astype(np.float32).astype(np.float64)
+    prob = fos.prepare(At, b.astype(np.float32))
+    assert prob.plan()["path"] == 0
+    lam = float(np.max(np.abs(A.T @ b)))
+    L = float(np.linalg.norm(A, 2) ** 2) if n <= 1024 else float(np.linalg.norm(A, "fro") ** 2)
+    alphas = [(lam * 0.4 * 0.7 ** i, 0.5 if i % 3 == 1 else 0.0) for i in range(nlam)]
+    xs = fos.fista_path(prob, None, alphas, max_iter=30, L=L)
+    assert len(xs) == nlam
+    for i, ((a1, a2), x) in enumerate(zip(alphas, xs)):
+        x_ref = orc.fista(A, b, "elasticnet", a1, a2, max_iter=30, L=L)
+        assert _data.rel(_np(x), x_ref) < TOL, (i, a1, a2)
+        if i in (0, nlam - 1):
+            x_one = fos.fista(prob, None, "elasticnet", a1, a2, max_iter=30, L=L)
+            assert _data.rel(_np(x), _np(x_one)) < 1e-6, (i, a1, a2)
+    xd = fos.fista_path(prob, None, alphas, max_iter=20, L=L, delta=3.0)
+    assert _data.rel(_np(xd[2]), orc.fista_delta(A, b, "elasticnet", alphas[2][0], alphas[2][1], 3.0, max_iter=20, L=L)) < TOL
+    # the handles stay usable by the single-vector path afterwards (state machines are shared, y is rebuilt)
+    x_again = fos.fista_path(prob, None, alphas[:2], max_iter=30, L=L)
+    assert _data.rel(_np(x_again[0]), _np(xs[0])) < 1e-6
+
+
 def test_fista_path_falls_back_on_shapes_without_multi_kernel(fos):
     A, b, fx = _data.problem("ragged")          # two-pass path: no multi-vector kernel -> one by one, same answers
     lam = float(np.max(np.abs(A.T @ b)))

@@ -208,3 +208,76 @@ def test_two_ranks_every_flag_and_config5_in_miniature(tmp_path):
     Aq = torch.as_tensor(A.astype(np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
     x5_ref = orc.fista(Aq, b.astype(np.float32).astype(np.float64), "elasticnet", a1, 10.0, max_iter=40, L=L)
     assert _data.rel(r0["x5"], x5_ref) < TOL and _data.rel(r0["x5e"], x5_ref) < TOL
+
+
+# --------------------------------------------------------------------------------------------------
+# one-shot full-mesh all-reduce kernel (fos_comm_mesh_*): two processes, IPC-mapped inboxes, one GPU
+# --------------------------------------------------------------------------------------------------
+def _mesh_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import fastoptsolver_amd as fos
+    from fastoptsolver_amd import distributed as fd
+    comm = fd.Comm(dist.group.WORLD, transport="mesh")
+    out = {}
+    # (1) the kernel alone: floats and doubles, several sizes, many rounds back to back (the two inbox sets alternate)
+    ok = True
+    for count, dt in ((1, torch.float32), (513, torch.float32), (16385, torch.float32), (8193, torch.float64), (32768, torch.float64)):
+        for rnd in range(6):
+            g = torch.Generator(device="cuda").manual_seed(100 * rnd + count)
+            both = [torch.randn(count, device="cuda", dtype=dt, generator=g) for _ in range(world)]   # same on every rank
+            mine = both[rank].clone()
+            comm.allreduce(mine)
+            want = both[0].clone()
+            for r in range(1, world):
+                want += both[r]                                                  # rank order, like the kernel
+            ok = ok and bool(torch.equal(mine, want))
+    comm.check()
+    out["kernel_ok"] = np.asarray(ok)
+    # (2) the whole sharded stack on it: enqueue-only FISTA, every flag, L-BFGS
+    A, b, _ = _data.synth(*SHAPE)
+    a1, a2 = _weights(A, b)
+    lo, hi = fd.shard_rows(A.shape[0], world, rank)
+    As, bs = A[lo:hi].astype(np.float32), b[lo:hi].astype(np.float32)
+    eng = fd.HipShardEngine(As, bs, comm=comm)
+    np.random.seed(0)
+    L = fos.estimate_lipschitz(eng.prob)
+    out["L"] = np.asarray(L)
+    eng.reset(tau=1.0 / (L + a2), alpha1=a1, alpha2=a2)
+    fd.ShardedFista(eng).run(40)
+    out["x"] = eng.x().cpu().numpy()
+    x, h = fos.fista(As, bs, "elasticnet", a1, a2, max_iter=40, L=L, return_history=True, backtracking=True,
+                     t_init_factor=2.0, comm=comm)
+    out["xbt"], out["objbt"] = np.asarray(x), np.asarray(h["obj"])
+    s = fos.LBFGSSolver("ridge", 0.0, a2).fit(As, bs, comm=comm)
+    out["xl"], out["nfev"] = np.asarray(s.x_), np.asarray(s.nfev_)
+    comm.check()
+    np.savez(os.path.join(out_dir, f"m{rank}.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_one_shot_mesh_allreduce_two_processes(tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_mesh_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "m0.npz"), np.load(tmp_path / "m1.npz")
+    assert bool(r0["kernel_ok"]) and bool(r1["kernel_ok"])
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), f"replicas drifted apart: {k}"
+    A, b, _ = _data.synth(*SHAPE)
+    a1, a2 = _weights(A, b)
+    np.random.seed(0)
+    L_ref = orc.estimate_lipschitz(A, v0=np.random.randn(A.shape[1]))
+    L = float(r0["L"])
+    assert L == pytest.approx(L_ref, rel=TOL)
+    assert _data.rel(r0["x"], orc.fista(A, b, "elasticnet", a1, a2, max_iter=40, L=L)) < TOL
+    x_ref, h_ref = orc.fista(A, b, "elasticnet", a1, a2, max_iter=40, L=L, return_history=True, backtracking=True,
+                             t_init_factor=2.0)
+    assert _data.rel(r0["xbt"], x_ref) < TOL and np.allclose(r0["objbt"], h_ref["obj"], rtol=TOL)
+    ref = orc.LBFGSSolver("ridge", 0.0, a2).fit(A, b)
+    assert _data.rel(r0["xl"], ref.x_) < TOL and int(r0["nfev"]) == ref.nfev_
