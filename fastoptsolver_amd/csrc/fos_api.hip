@@ -1655,7 +1655,9 @@ int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters) {
   for (int v = 0; v < nv; ++v) all_plain = all_plain && plain_run(fs[v]);
   const bool streaming = p->path == 0 && !p->tall && !p->comm && !p->resident && all_plain;
   MultiLaunch fn = (streaming && p->dtype == FOS_F32 && p->entry != &kWideF32) ? find_multi(p->n, nv) : nullptr;
-  if (!fn && streaming && p->entry != &kWideF32) {
+  // the two-product pass costs about two single-vector passes per iteration whatever the number of weights: it pays
+  // from three weights on (profiles/r02_multilambda.md); two weights without a VALU multi-vector kernel run one by one
+  if (!fn && streaming && p->entry != &kWideF32 && nv >= 3) {
     if (iters == 0) return FOS_OK;
     return run_multi_mfma(fs, nv, iters);          // 5..16 weights, n up to 16384, fp32 and bf16
   }
