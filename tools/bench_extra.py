@@ -46,12 +46,12 @@ def main():
     wall = time.perf_counter() - t0
     met = fos.get_metrics()
     n = cfg["n"]
-    S = torch.randn(10, n, device=dev)
-    Y = S + 0.1 * torch.randn(10, n, device=dev)
-    g = torch.randn(n, device=dev)
-    d = torch.empty(n, device=dev)
-    two_loop = timed_us(lambda: lib.fos_lbfgs_two_loop(_core.ptr(g), _core.ptr(S), _core.ptr(Y), 10, 0, 10, n, _core.ptr(d),
-                                                       _core.stream_ptr()), 200)
+    S = torch.randn(10, n, device=dev, dtype=torch.float64)
+    Y = S + 0.1 * torch.randn(10, n, device=dev, dtype=torch.float64)
+    g = torch.randn(n, device=dev, dtype=torch.float64)
+    d = torch.empty(n, device=dev, dtype=torch.float64)
+    two_loop = timed_us(lambda: lib.fos_lbfgs_two_loop_dd(_core.ptr(g), _core.ptr(S), _core.ptr(Y), 10, 0, 10, n,
+                                                          _core.ptr(d), _core.stream_ptr()), 200)
     b_fg = cfg["m"] * n * 4 + 4 * cfg["m"] + 8 * n
     out["cfg3_lbfgs"] = dict(nit=s.nit_, nfev=s.nfev_, task=s.task_, wall_s=wall, it_per_s=s.nit_ / wall,
                              fg_per_s_wall=s.nfev_ / wall, fg_device_mean_us=met["grad_time_mean"] * 1e6,
