@@ -262,6 +262,12 @@ struct fos_problem {
   int path = 0;                      // 0 fused, 1 two-pass fallback
   bool resident = false;             // small enough for the single-launch LDS-resident loop (resident.hpp)
   bool tall = false;                 // n <= 64: row-per-thread single pass (gemv_tall.hpp); no alignment requirements
+  // Rows wider than one workgroup's registers / LDS (fp32 > 32768 columns, bf16 > 16384): column blocks of cb_width
+  // columns through the streaming kernel in two phases, r = A y - b block by block, then A^T r block by block
+  bool colblock = false;
+  int64_t cb_width = 0;
+  float* rneg = nullptr;             // m floats: the negated residual between the two phases
+  float* zeros = nullptr;            // cb_width floats of zeros (phase 2 runs the same kernel with y = 0, b = -r)
   int64_t slab_stride = 0;           // floats between slab rows (0 = n); the tall pass pads rows to a multiple of 4
   const MenuEntry* entry = nullptr;
   int nwg = 0;                       // workgroups of the fused kernel
@@ -384,7 +390,7 @@ int ensure_workspace(fos_problem* p) {
     HIP_TRY(hipMalloc(&p->slabs, (size_t)need_slabs * (p->slab_stride ? p->slab_stride : p->n) * sizeof(float)));
     p->slab_cap = need_slabs;
   }
-  const int need_rr = std::max(p->nwg, std::max(p->resid_grid, 1));
+  const int need_rr = std::max(std::max(p->nwg, p->colblock ? 256 : 1), std::max(p->resid_grid, 1));
   if (need_rr > p->rr_cap) {
     if (p->rr_part) (void)hipFree(p->rr_part);
     if (p->rr2_part) (void)hipFree(p->rr2_part);
@@ -395,6 +401,11 @@ int ensure_workspace(fos_problem* p) {
     p->rr_cap = need_rr;
   }
   if (p->path == 1 && p->rvec == nullptr) HIP_TRY(hipMalloc(&p->rvec, (size_t)p->m * sizeof(double)));
+  if (p->colblock && p->rneg == nullptr) {
+    HIP_TRY(hipMalloc(&p->rneg, (size_t)p->m * sizeof(float)));
+    HIP_TRY(hipMalloc(&p->zeros, (size_t)p->cb_width * sizeof(float)));
+    HIP_TRY(hipMemset(p->zeros, 0, (size_t)p->cb_width * sizeof(float)));
+  }
   return FOS_OK;
 }
 
@@ -444,7 +455,59 @@ int launch_pass(fos_problem* p, const YSource& ys, const float* b, bool with_g, 
   return prof_mark(p, false);
 }
 
+__global__ __launch_bounds__(256) void sumsq_partials_kernel(const float* __restrict__ v, int64_t m, double* __restrict__ part,
+                                                            const int* stopped) {
+  if (stopped != nullptr && *stopped != 0) return;
+  __shared__ double ws[4];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) acc += (double)v[i] * (double)v[i];
+  acc = fos::wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+// Column blocks (rows wider than any single-pass kernel): phase 1 accumulates the negated residual block by block with the
+// residual-only form of the streaming kernel, phase 2 is the SAME with-gradient kernel per block with y = 0 and b = -r
+// (its row "dot" is then exactly r_i), writing its columns of full-width slabs.  A is read twice, at streaming speed.
+int launch_pass_colblock(fos_problem* p, const YSource& ys, const float* b, bool with_g, int* n_rr) {
+  const int64_t W = p->cb_width, esz = p->dtype == FOS_F32 ? 4 : 2;
+  const int nblk = (int)((p->n + W - 1) / W);
+  const char* Ab = reinterpret_cast<const char*>(p->A);
+  for (int cb = 0; cb < nblk; ++cb) {
+    const int64_t c0 = cb * W;
+    const int nb = (int)std::min<int64_t>(W, p->n - c0);
+    YSource yb = ys;
+    if (ys.y) yb.y = ys.y + c0;
+    if (ys.x_cur) { yb.x_cur = ys.x_cur + c0; yb.x_prev = ys.x_prev + c0; }
+    if (ys.yd) yb.yd = ys.yd + c0;
+    yb.res_out = p->rneg;
+    yb.res_accum = cb > 0;
+    p->entry->resid_only(Ab + c0 * esz, p->lda, cb == 0 ? b : nullptr, p->m, nb, yb, p->rows_per_wg, p->slabs, p->rr2_part,
+                         p->rr2_part, p->nwg, p->stream);
+    LAUNCH_CHECK();
+  }
+  if (!with_g) {
+    hipLaunchKernelGGL(sumsq_partials_kernel, dim3(256), dim3(256), 0, p->stream, p->rneg, p->m, p->rr_part, ys.stopped);
+    LAUNCH_CHECK();
+    *n_rr = 256;
+    return FOS_OK;
+  }
+  for (int cb = 0; cb < nblk; ++cb) {
+    const int64_t c0 = cb * W;
+    const int nb = (int)std::min<int64_t>(W, p->n - c0);
+    YSource yz{p->zeros, nullptr, nullptr, nullptr, ys.stopped};
+    yz.slab_stride = p->n;
+    p->entry->with_g(Ab + c0 * esz, p->lda, p->rneg, p->m, nb, yz, p->rows_per_wg, p->slabs + c0, cb == 0 ? p->rr_part : p->rr2_part,
+                     p->rr2_part, p->nwg, p->stream);
+    LAUNCH_CHECK();
+  }
+  *n_rr = p->nwg;
+  return FOS_OK;
+}
+
 int launch_pass_inner(fos_problem* p, const YSource& ys, const float* b, bool with_g, int* n_rr, bool dual) {
+  if (p->path == 0 && p->colblock) return launch_pass_colblock(p, ys, b, with_g, n_rr);
   if (p->path == 0) {
     FusedLaunch fn = dual ? p->entry->dual : (with_g ? p->entry->with_g : p->entry->resid_only);
     fn(p->A, p->lda, b, p->m, (int)p->n, ys, p->rows_per_wg, p->slabs, p->rr_part, p->rr2_part, p->nwg, p->stream);
@@ -643,6 +706,7 @@ void apply_plan(fos_problem* p, unsigned flags) {
   const int64_t m = p->m, n = p->n;
   p->plan_flags = flags;
   p->tall = false;
+  p->colblock = false;
   p->slab_stride = 0;
   p->vec4 = (n % 4 == 0);
   p->allow_resident = !(flags & FOS_PLAN_NO_RESIDENT);
@@ -654,7 +718,14 @@ void apply_plan(fos_problem* p, unsigned flags) {
     plan_tall(p, tall_entry(p->dtype, n, p->lda, p->A));
   else if (e) plan_fused(p, e, 0);
   else if (vec_ok && p->dtype == FOS_F32 && n <= fos::WD_MAX_N && !(flags & FOS_PLAN_NO_WIDE)) plan_fused(p, &kWideF32, 0);
-  else plan_fallback(p);
+  else if (vec_ok && !(flags & FOS_PLAN_NO_COLBLOCK)) {
+    // column blocks of equal width (a multiple of 64 columns, at most the widest streaming geometry)
+    const int64_t cap = 16384;
+    const int64_t blocks = (n + cap - 1) / cap;
+    p->cb_width = ((n + blocks - 1) / blocks + 63) / 64 * 64;
+    plan_fused(p, default_entry(p->dtype, p->cb_width), 0);
+    p->colblock = true;
+  } else plan_fallback(p);
 }
 
 // ---- fp64-accumulating pass (L-BFGS fg) -----------------------------------------------------------------------------
@@ -884,7 +955,7 @@ int fos_problem_set_stream(fos_problem* p, void* stream) {
 
 int fos_problem_replan(fos_problem* p, unsigned flags) {
   if (!p) return fail(FOS_ERR_ARG, "fos_problem_replan: null");
-  if (flags & ~(unsigned)(FOS_PLAN_NO_RESIDENT | FOS_PLAN_NO_TALL | FOS_PLAN_NO_WIDE))
+  if (flags & ~(unsigned)(FOS_PLAN_NO_RESIDENT | FOS_PLAN_NO_TALL | FOS_PLAN_NO_WIDE | FOS_PLAN_NO_COLBLOCK))
     return fail(FOS_ERR_ARG, "fos_problem_replan: unknown flag");
   // workspace sized for the old plan (slab stride, fp64 slabs) is dropped and rebuilt
   void* drop[] = {p->slabs, p->rr_part, p->rr2_part, p->slabs_dd, p->rr_dd};
@@ -920,7 +991,7 @@ int fos_problem_destroy(fos_problem* p) {
   if (!p) return FOS_OK;
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   void* bufs[] = {p->slabs, p->rr_part, p->rr2_part, p->rvec, p->gbuf_own, p->ybuf, p->dscal, p->part, p->xp, p->q_part, p->bt_out,
-                  p->slabs_dd, p->rr_dd, p->lhist, p->rbuf16, p->slabs16};
+                  p->slabs_dd, p->rr_dd, p->lhist, p->rbuf16, p->slabs16, p->rneg, p->zeros};
   for (void* q : bufs)
     if (q) (void)hipFree(q);
   delete p;
@@ -935,7 +1006,7 @@ int fos_problem_plan(const fos_problem* p, int32_t plan[8]) {
   plan[3] = p->entry ? p->entry->r : 0;
   plan[4] = p->nwg;
   plan[5] = p->nslabs;
-  plan[6] = (p->path == 0 ? 1 : 0) | (p->resident ? 2 : 0) | (p->tall ? 4 : 0);
+  plan[6] = (p->path == 0 ? 1 : 0) | (p->resident ? 2 : 0) | (p->tall ? 4 : 0) | (p->colblock ? 8 : 0);
   plan[7] = p->ncu;
   return FOS_OK;
 }
@@ -948,7 +1019,7 @@ int fos_problem_tune(fos_problem* p, int threads, int chunks, int rows, int work
     p->nslabs = p->nwg;
     return ensure_workspace(p);
   }
-  if (p->path != 0 || p->tall)
+  if (p->path != 0 || p->tall || p->colblock)
     return fail(FOS_ERR_UNSUPPORTED, "fos_problem_tune: only the streaming single-pass kernel has a geometry menu");
   const MenuEntry* e = find_entry(p->dtype, threads, chunks, rows);
   if (!e || (int64_t)e->threads * e->k * epc_of(p->dtype) < p->n)
@@ -1417,7 +1488,7 @@ int fos_fista_run_history(fos_fista* f, int iters, double* x_hist, double* hist,
     return fail(FOS_ERR_ARG, "fos_fista_run_history: bad argument");
   fos_problem* p = f->p;
   if (plain_run(f) && p->resident) return iters == 0 ? FOS_OK : run_resident(f, iters, x_hist, hist);
-  if (!plain_run(f) || p->path != 0 || p->entry->dual == nullptr || p->comm != nullptr)
+  if (!plain_run(f) || p->path != 0 || p->colblock || p->entry->dual == nullptr || p->comm != nullptr)
     return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_history: needs a plain run on the fused path with a DUAL kernel");
   if (iters == 0) return FOS_OK;
   bool stopped = false;
@@ -1653,7 +1724,7 @@ int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters) {
   fos_problem* p = fs[0]->p;
   bool all_plain = true;
   for (int v = 0; v < nv; ++v) all_plain = all_plain && plain_run(fs[v]);
-  const bool streaming = p->path == 0 && !p->tall && !p->comm && !p->resident && all_plain;
+  const bool streaming = p->path == 0 && !p->tall && !p->colblock && !p->comm && !p->resident && all_plain;
   MultiLaunch fn = (streaming && p->dtype == FOS_F32 && p->entry != &kWideF32) ? find_multi(p->n, nv) : nullptr;
   // the two-product pass costs about two single-vector passes per iteration whatever the number of weights: it pays
   // from three weights on (profiles/r02_multilambda.md); two weights without a VALU multi-vector kernel run one by one
@@ -1744,7 +1815,7 @@ int fos_fista_grad_dual(fos_fista* f) {
   fos_problem* p = f->p;
   int n_rr = 0, rc;
   if ((rc = flush_pending(f))) return rc;
-  if (p->path == 0 && p->entry->dual != nullptr) {
+  if (p->path == 0 && !p->colblock && p->entry->dual != nullptr) {
     if ((rc = launch_pass(p, fista_source(f), p->b, true, &n_rr, true))) return rc;
     if ((rc = launch_slab_reduce(p, n_rr, p->gbuf, &f->scal->rr, &f->scal->stopped))) return rc;
     hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->rr2_part, n_rr, 1,

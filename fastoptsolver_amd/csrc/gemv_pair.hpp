@@ -44,6 +44,10 @@ struct YSource {
   const int* stopped;    // device flag: non-zero -> kernel is a no-op (solver already stopped)
   double beta_val;
   const double* yd;      // explicit y in fp64 (L-BFGS iterate); used when y == nullptr and x_cur == nullptr
+  // Column-blocked passes over rows too wide for one workgroup's registers (fos_api.hip "column blocks"):
+  float* res_out;        // nullable: the NEGATED residual of every row, res_out[i] = (res_accum ? res_out[i] : 0) - s_i
+  int res_accum;
+  int64_t slab_stride;   // floats between consecutive slab rows (0 = n): a block writes its columns of full-width slabs
 };
 
 __device__ inline double source_beta(const YSource& ys) {
@@ -302,6 +306,8 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
         s = (ACC)0;
       }
       res[r] = s;
+      if (ys.res_out != nullptr && tid == 0 && row < row_hi)
+        ys.res_out[row] = (ys.res_accum ? ys.res_out[row] : 0.f) - (float)s;
       if constexpr (DUAL) {
         ACC s2 = (ACC)0;
 #pragma unroll
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
   }
 
   // ---- epilogue: this workgroup's slab -------------------------------------------------------------
-  ACC* slab = slabs + (int64_t)blockIdx.x * n;
+  ACC* slab = slabs + (int64_t)blockIdx.x * (ys.slab_stride ? ys.slab_stride : (int64_t)n);
 #pragma unroll
   for (int c = 0; c < K; ++c) {
     if (WITH_G && live[c]) {

@@ -31,7 +31,7 @@ enum { FOS_MODE_FISTA = 0, FOS_MODE_DELTA = 1, FOS_MODE_ISTA = 2 };
 enum { FOS_PROX_L1 = 0, FOS_PROX_ENET = 1 };
 enum { FOS_STOP_NONE = 0, FOS_STOP_STEP = 1, FOS_STOP_RATIO = 2, FOS_STOP_GRAD = 3 };
 
-enum { FOS_PLAN_NO_RESIDENT = 1, FOS_PLAN_NO_TALL = 2, FOS_PLAN_NO_WIDE = 4 };   /* fos_problem_replan */
+enum { FOS_PLAN_NO_RESIDENT = 1, FOS_PLAN_NO_TALL = 2, FOS_PLAN_NO_WIDE = 4, FOS_PLAN_NO_COLBLOCK = 8 };   /* fos_problem_replan */
 
 typedef struct fos_problem fos_problem;   /* A, b, launch plan, workspace            */
 typedef struct fos_comm fos_comm;         /* communicator of a row-sharded problem   */
@@ -83,11 +83,13 @@ int fos_problem_set_stream(fos_problem* p, void* stream);
 /* plan[0..7] = {path (0 fused single pass, 1 two-pass fallback), threads, chunks/thread, rows/step,
  *               workgroups, slabs, flags (bit 0: non-temporal loads; bit 1: small enough for the single-launch
  *               LDS-resident loop that fos_fista_run / _run_history / fos_power_iter then use; bit 2: n <= 64, the
- *               single pass is the row-per-thread kernel, which has no alignment requirements), CUs} */
+ *               single pass is the row-per-thread kernel, which has no alignment requirements; bit 3: rows wider than
+ *               any single-pass kernel - column blocks through the streaming kernel in two phases, A read twice), CUs} */
 int fos_problem_plan(const fos_problem* p, int32_t plan[8]);
 /* Re-run the planner with kernel families switched off (FOS_PLAN_* bits): NO_RESIDENT keeps small problems off the
  * one-launch LDS-resident loop, NO_TALL keeps n <= 64 off the row-per-thread pass, NO_WIDE keeps 16384 < n <= 32768 off
- * the y-in-LDS pass; each then takes the next family that fits (streaming single pass, two-pass).  For tests and
+ * the y-in-LDS pass, NO_COLBLOCK keeps wider rows off the column-blocked streaming passes; each then takes the next
+ * family that fits (streaming single pass, column blocks, two-pass).  For tests and
  * A/B measurements; call before creating fos_fista handles on the problem.  Synchronises (reallocates workspace). */
 int fos_problem_replan(fos_problem* p, unsigned flags);
 /* Benchmark/tuning override of the fused-kernel geometry; returns FOS_ERR_UNSUPPORTED if not instantiated. */

@@ -598,17 +598,25 @@ def test_bf16_elastic_net_fista_vs_oracle_on_rounded_A(fos):
     assert xt_.dtype == torch.float32 and _data.rel(xt_.cpu().numpy(), x_ref) < TOL
 
 
-@pytest.mark.parametrize("m,n,path", [(96, 20000, 0), (700, 32768, 0), (257, 24580, 0), (3, 16388, 0), (64, 40000, 1)])
-def test_wide_rows(fos, m, n, path):
+@pytest.mark.parametrize("m,n,kind", [(96, 20000, "wide"), (700, 32768, "wide"), (257, 24580, "wide"), (3, 16388, "wide"),
+                                      (64, 40000, "colblock"), (130, 65536, "colblock"), (300, 32772, "colblock"),
+                                      (50, 40001, "twopass")])
+def test_wide_rows(fos, m, n, kind):
     """Rows beyond the streaming kernel's register budget (fp32: 16384 columns): up to 32768 columns the single pass keeps
-    y in LDS (gemv_wide.hpp); wider still takes the two-pass kernels."""
+    y in LDS (gemv_wide.hpp); wider aligned rows run COLUMN BLOCKS through the streaming kernel in two phases (r = A y - b
+    block by block, then A^T r block by block: A read twice at streaming speed); ragged widths take the two-pass kernels."""
     rng = np.random.default_rng(m + n)
     A = rng.standard_normal((m, n)).astype(np.float32)
     b = rng.standard_normal(m).astype(np.float32)
     y = rng.standard_normal(n).astype(np.float32)
-    prob = fos.prepare(A, b)
+    prob = fos.prepare(A, b, pad=False)
     plan = prob.plan()
-    assert plan["path"] == path and (path == 1 or (plan["threads"], plan["chunks"]) == (512, 16)), plan
+    if kind == "wide":
+        assert plan["path"] == 0 and (plan["threads"], plan["chunks"]) == (512, 16) and plan["colblock"] == 0, plan
+    elif kind == "colblock":
+        assert plan["path"] == 0 and plan["colblock"] == 1, plan
+    else:
+        assert plan["path"] == 1, plan
     A64, b64 = A.astype(np.float64), b.astype(np.float64)
     g = prob.gemv_pair(_dev(y), alpha2=0.0).cpu().numpy()
     g_ref, rr_ref = orc.gram_gradient(A64, y.astype(np.float64), b64, 0.0)
