@@ -287,6 +287,12 @@ class Fista:
         with self.prob.ctx():
             _lib.check(self.lib.fos_fista_reset(self.h, C.byref(p), ptr(x0)), "fos_fista_reset")
 
+    def set_precise(self, on=True):
+        """Split-form gradient from the fp64-accumulating pass at the unrounded y_k (fos_fista_set_precise)."""
+        with self.prob.ctx():
+            _lib.check(self.lib.fos_fista_set_precise(self.h, int(bool(on))), "fos_fista_set_precise")
+        self.precise = bool(on)
+
     def set_tau(self, tau):
         _lib.check(self.lib.fos_fista_set_tau(self.h, float(tau)), "fos_fista_set_tau")
 

@@ -37,7 +37,7 @@ static_assert(BT_COLS % 16 == 0 && BT_A_LOADS >= 1 && BT_X_LOADS >= 1, "tile sha
 
 // Candidate generation: dlt_j (fp64 -> fp32, written in Xp layout) and per-candidate sums.
 // part[wg] = { gd_j (16), dd_j (16), nnz_j (16), ||grad||^2, ||y||^2 }.
-__global__ __launch_bounds__(256) void fista_trial_batch_kernel(const float* __restrict__ gbuf, int n, int n_pad,
+__global__ __launch_bounds__(256) void fista_trial_batch_kernel(GradSrc gsrc, int n, int n_pad,
                                                                const double* __restrict__ x_cur,
                                                                const double* __restrict__ x_prev,
                                                                const FistaScalars* __restrict__ scal, FistaParams prm,
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void fista_trial_batch_kernel(const float* __r
   for (int col = blockIdx.x * 256 + threadIdx.x; col < n_pad; col += gridDim.x * 256) {
     if (col < n) {
       const double y = form_y(x_cur[col], x_prev[col], beta);
-      double gf = (double)gbuf[col];
+      double gf = grad_at(gsrc, col);
       if (prm.prox_kind == PROX_L1 && prm.alpha2 > 0.0) gf += prm.alpha2 * y;
       g2 += gf * gf;
       y2 += y * y;
@@ -243,7 +243,7 @@ constexpr int BQ_COLS = 128;                         // Xq is zero-padded to a m
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 // Candidate generation for the bf16 path: same sums as fista_trial_batch_kernel, dlt_j written as three bf16 terms.
-__global__ __launch_bounds__(256) void fista_trial_batch_bf16_kernel(const float* __restrict__ gbuf, int n, int n_pad,
+__global__ __launch_bounds__(256) void fista_trial_batch_bf16_kernel(GradSrc gsrc, int n, int n_pad,
                                                                     const double* __restrict__ x_cur,
                                                                     const double* __restrict__ x_prev,
                                                                     const FistaScalars* __restrict__ scal,
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void fista_trial_batch_bf16_kernel(const float
     double y = 0.0, gf = 0.0;
     if (col < n) {
       y = form_y(x_cur[col], x_prev[col], beta);
-      gf = (double)gbuf[col];
+      gf = grad_at(gsrc, col);
       if (prm.prox_kind == PROX_L1 && prm.alpha2 > 0.0) gf += prm.alpha2 * y;
       g2 += gf * gf;
       y2 += y * y;

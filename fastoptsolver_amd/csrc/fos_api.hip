@@ -332,6 +332,10 @@ struct fos_fista {
   double *x_cur = nullptr, *x_prev = nullptr;   // fp64 iterate state
   float* dlt = nullptr;                         // trial difference vector x_tmp - y_k (fp32)
   fos::FistaScalars* scal = nullptr;
+  // precise mode (fos_fista_set_precise): the split-form gradient comes from the fp64-accumulating pass at the unrounded
+  // fp64 y_k, so that the Armijo comparison g(x_tmp) <= g(y) + C grad.dlt is decided on fp64-accurate terms
+  bool precise = false;
+  double* gbuf64 = nullptr;          // n + 4 doubles: [gradient ; ||r||^2]
   double* out5 = nullptr;            // device
   int nupd = 0;                      // workgroups of the update kernel
 };
@@ -1072,22 +1076,11 @@ int fos_gemv_pair_f64(fos_problem* p, const double* y, double alpha2, float* gra
   return FOS_OK;
 }
 
-int fos_gemv_pair_dd(fos_problem* p, const double* x, double alpha2, double* grad_rr) {
-  if (!p || !x || !grad_rr) return fail(FOS_ERR_ARG, "fos_gemv_pair_dd: null");
-  if (p->resident) {                           // small problem: one launch, fp64 throughout (resident.hpp)
-    if (p->dtype == FOS_F32)
-      hipLaunchKernelGGL((fos::gemv_pair_resident_kernel<float, double>), dim3(1), dim3(fos::RS_THREADS), 0, p->stream,
-                         (const float*)p->A, p->lda, p->b, (int)p->m, (int)p->n, x, alpha2, grad_rr, grad_rr + p->n);
-    else
-      hipLaunchKernelGGL((fos::gemv_pair_resident_kernel<fos::bf16_t, double>), dim3(1), dim3(fos::RS_THREADS), 0,
-                         p->stream, (const fos::bf16_t*)p->A, p->lda, p->b, (int)p->m, (int)p->n, x, alpha2, grad_rr,
-                         grad_rr + p->n);
-    LAUNCH_CHECK();
-    return FOS_OK;
-  }
+// The fp64-accumulating pass for any y source: out[0..n) = A^T (A y - b) + alpha2*l2vec (l2vec may be NULL when alpha2 = 0),
+// out[n] = ||A y - b||^2, summed over the ranks of a sharded problem.  Not for resident-planned problems (callers check).
+static int launch_pass_dd(fos_problem* p, const YSource& ys, double alpha2, const double* l2vec, double* out) {
   int rc = ensure_dd(p);
   if (rc) return rc;
-  YSource ys{nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, x};
   int nslabs = 0, n_rr = 0;
   int64_t stride = p->n;
   if ((rc = prof_mark(p, true))) return rc;
@@ -1104,12 +1097,12 @@ int fos_gemv_pair_dd(fos_problem* p, const double* x, double alpha2, double* gra
       hipLaunchKernelGGL(fos::residual_rows_kernel<float>, dim3(p->dd_nwg), dim3(256), 0, p->stream, (const float*)p->A,
                          p->lda, p->b, p->m, (int)p->n, ys, p->rvec, p->rr_dd);
       hipLaunchKernelGGL((fos::transpose_rows_kernel<float, double>), grid, dim3(256), 0, p->stream, (const float*)p->A,
-                         p->lda, p->m, (int)p->n, p->rvec, (const int*)nullptr, p->dd_rows_per_wg, p->slabs_dd);
+                         p->lda, p->m, (int)p->n, p->rvec, ys.stopped, p->dd_rows_per_wg, p->slabs_dd);
     } else {
       hipLaunchKernelGGL(fos::residual_rows_kernel<fos::bf16_t>, dim3(p->dd_nwg), dim3(256), 0, p->stream,
                          (const fos::bf16_t*)p->A, p->lda, p->b, p->m, (int)p->n, ys, p->rvec, p->rr_dd);
       hipLaunchKernelGGL((fos::transpose_rows_kernel<fos::bf16_t, double>), grid, dim3(256), 0, p->stream,
-                         (const fos::bf16_t*)p->A, p->lda, p->m, (int)p->n, p->rvec, (const int*)nullptr, p->dd_rows_per_wg,
+                         (const fos::bf16_t*)p->A, p->lda, p->m, (int)p->n, p->rvec, ys.stopped, p->dd_rows_per_wg,
                          p->slabs_dd);
     }
     nslabs = p->dd_two_pass_chunks;
@@ -1120,9 +1113,26 @@ int fos_gemv_pair_dd(fos_problem* p, const double* x, double alpha2, double* gra
   // sharded: alpha2*x enters the sum over the ranks exactly once (rank 0 adds it to its partial)
   const double a2_here = (p->comm && p->comm->rank != 0) ? 0.0 : alpha2;
   hipLaunchKernelGGL(fos::slab_reduce_dd_kernel, dim3((unsigned)((p->n + 127) / 128)), dim3(256), 0, p->stream, p->slabs_dd,
-                     nslabs, (int)p->n, stride, p->rr_dd, n_rr, a2_here, x, grad_rr);
+                     nslabs, (int)p->n, stride, p->rr_dd, n_rr, a2_here, l2vec, out, ys.stopped);
   LAUNCH_CHECK();
-  return reduce_across(p, grad_rr, (size_t)p->n + 1, true);
+  return reduce_across(p, out, (size_t)p->n + 1, true);
+}
+
+int fos_gemv_pair_dd(fos_problem* p, const double* x, double alpha2, double* grad_rr) {
+  if (!p || !x || !grad_rr) return fail(FOS_ERR_ARG, "fos_gemv_pair_dd: null");
+  if (p->resident) {                           // small problem: one launch, fp64 throughout (resident.hpp)
+    if (p->dtype == FOS_F32)
+      hipLaunchKernelGGL((fos::gemv_pair_resident_kernel<float, double>), dim3(1), dim3(fos::RS_THREADS), 0, p->stream,
+                         (const float*)p->A, p->lda, p->b, (int)p->m, (int)p->n, x, alpha2, grad_rr, grad_rr + p->n);
+    else
+      hipLaunchKernelGGL((fos::gemv_pair_resident_kernel<fos::bf16_t, double>), dim3(1), dim3(fos::RS_THREADS), 0,
+                         p->stream, (const fos::bf16_t*)p->A, p->lda, p->b, (int)p->m, (int)p->n, x, alpha2, grad_rr,
+                         grad_rr + p->n);
+    LAUNCH_CHECK();
+    return FOS_OK;
+  }
+  YSource ys{nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, x};
+  return launch_pass_dd(p, ys, alpha2, x, grad_rr);
 }
 
 int fos_residual_objective(fos_problem* p, const float* x, double* out3) {
@@ -1283,7 +1293,7 @@ int fos_fista_create(fos_problem* p, fos_fista** out) {
 
 int fos_fista_destroy(fos_fista* f) {
   if (!f) return FOS_OK;
-  void* bufs[] = {f->x_cur, f->x_prev, f->dlt, f->scal, f->out5, f->part2, f->ynext};
+  void* bufs[] = {f->x_cur, f->x_prev, f->dlt, f->scal, f->out5, f->part2, f->ynext, f->gbuf64};
   for (void* q : bufs)
     if (q) (void)hipFree(q);
   delete f;
@@ -1338,6 +1348,22 @@ int fos_fista_set_tau(fos_fista* f, double tau) {
   return FOS_OK;
 }
 
+static fos::GradSrc grad_src(const fos_fista* f) {
+  return fos::GradSrc{f->p->gbuf, f->precise ? f->gbuf64 : nullptr};
+}
+
+int fos_fista_set_precise(fos_fista* f, int on) {
+  if (!f) return fail(FOS_ERR_ARG, "fos_fista_set_precise: null");
+  if (on && !f->gbuf64) HIP_TRY(hipMalloc(&f->gbuf64, (size_t)(f->p->n + 4) * sizeof(double)));
+  f->precise = on != 0;
+  return FOS_OK;
+}
+
+__global__ void rr_from_gbuf64_kernel(const double* __restrict__ g64, int n, double* __restrict__ rr_out, const int* stopped) {
+  if (stopped != nullptr && *stopped != 0) return;
+  *rr_out = g64[n];
+}
+
 static YSource fista_source(fos_fista* f) {
   return YSource{nullptr, f->x_cur, f->x_prev, &f->scal->beta, &f->scal->stopped, 0.0};
 }
@@ -1374,11 +1400,11 @@ static void launch_update_from_slabs(fos_fista* f, double* part, int host_beta, 
   if (nslabs == 0) nslabs = p->nslabs;
   if (p->vec4)
     hipLaunchKernelGGL((fos::fista_update_kernel<true, true>), dim3(f->nupd), dim3(256), 0, p->stream, slabs,
-                       nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
+                       nslabs, fos::GradSrc{nullptr, nullptr}, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
                        beta_val, x_hist, y_next, beta_next, slab_stride, y_mode, y_slot);
   else
     hipLaunchKernelGGL((fos::fista_update_kernel<true, false>), dim3(f->nupd), dim3(256), 0, p->stream, slabs,
-                       nslabs, (const float*)nullptr, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
+                       nslabs, fos::GradSrc{nullptr, nullptr}, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
                        beta_val, x_hist, y_next, beta_next, slab_stride, y_mode, y_slot);
 }
 
@@ -1413,7 +1439,7 @@ static bool plain_run(const fos_fista* f) {
 // The gradient-norm stop sits between the reduced gradient and the update (fos_fista_params.tol_grad).
 static int launch_grad_norm_stop(fos_fista* f) {
   fos_problem* p = f->p;
-  hipLaunchKernelGGL(fos::grad_norm_stop_kernel, dim3(1), dim3(1024), 0, p->stream, p->gbuf, (int)p->n, f->x_cur, f->x_prev,
+  hipLaunchKernelGGL(fos::grad_norm_stop_kernel, dim3(1), dim3(1024), 0, p->stream, grad_src(f), (int)p->n, f->x_cur, f->x_prev,
                      f->scal, f->prm);
   LAUNCH_CHECK();
   return FOS_OK;
@@ -1805,6 +1831,17 @@ int fos_fista_grad(fos_fista* f) {
   if (!f) return fail(FOS_ERR_ARG, "fos_fista_grad: null");
   fos_problem* p = f->p;
   int n_rr = 0, rc;
+  if (f->precise && !p->resident) {
+    // fp64-accumulating pass at the unrounded y_k = x_k + beta (x_k - x_{k-1}); alpha2*y is added by the consumers
+    YSource ys = (plain_run(f) && f->host_valid)
+                     ? YSource{nullptr, f->x_cur, f->x_prev, nullptr, &f->scal->stopped, f->h_beta, nullptr}
+                     : fista_source(f);
+    if ((rc = launch_pass_dd(p, ys, 0.0, nullptr, f->gbuf64))) return rc;
+    hipLaunchKernelGGL(rr_from_gbuf64_kernel, dim3(1), dim3(1), 0, p->stream, f->gbuf64, (int)p->n, &f->scal->rr,
+                       &f->scal->stopped);
+    LAUNCH_CHECK();
+    return FOS_OK;
+  }
   const YSource ys = (plain_run(f) && f->host_valid) ? plain_source(f) : fista_source(f);
   if ((rc = launch_pass(p, ys, p->b, true, &n_rr))) return rc;
   return launch_slab_reduce(p, n_rr, p->gbuf, &f->scal->rr, &f->scal->stopped);
@@ -1815,7 +1852,7 @@ int fos_fista_grad_dual(fos_fista* f) {
   fos_problem* p = f->p;
   int n_rr = 0, rc;
   if ((rc = flush_pending(f))) return rc;
-  if (p->path == 0 && !p->colblock && p->entry->dual != nullptr) {
+  if (p->path == 0 && !p->colblock && p->entry->dual != nullptr && !(f->precise && !p->resident)) {
     if ((rc = launch_pass(p, fista_source(f), p->b, true, &n_rr, true))) return rc;
     if ((rc = launch_slab_reduce(p, n_rr, p->gbuf, &f->scal->rr, &f->scal->stopped))) return rc;
     hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->rr2_part, n_rr, 1,
@@ -1855,11 +1892,11 @@ int fos_fista_update(fos_fista* f) {
   }
   if (p->vec4)
     hipLaunchKernelGGL((fos::fista_update_kernel<false, true>), dim3(f->nupd), dim3(256), 0, p->stream,
-                       (const float*)nullptr, 0, p->gbuf, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
+                       (const float*)nullptr, 0, grad_src(f), (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
                        beta_k, (double*)nullptr, y_next, beta_next);
   else
     hipLaunchKernelGGL((fos::fista_update_kernel<false, false>), dim3(f->nupd), dim3(256), 0, p->stream,
-                       (const float*)nullptr, 0, p->gbuf, (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
+                       (const float*)nullptr, 0, grad_src(f), (int)p->n, f->x_cur, f->x_prev, f->scal, f->prm, part, host_beta,
                        beta_k, (double*)nullptr, y_next, beta_next);
   LAUNCH_CHECK();
   if (plain) {
@@ -1881,7 +1918,7 @@ int fos_fista_trial(fos_fista* f, double t, int with_residual, double out8[8]) {
   { int rcf = flush_pending(f); if (rcf) return rcf; }
   const int grid = grid_1d(p->n, 256, 256);
   HIP_TRY(hipMemsetAsync(f->out5, 0, 8 * sizeof(double), p->stream));
-  hipLaunchKernelGGL(fos::fista_trial_kernel, dim3(grid), dim3(256), 0, p->stream, p->gbuf, (int)p->n, f->x_cur,
+  hipLaunchKernelGGL(fos::fista_trial_kernel, dim3(grid), dim3(256), 0, p->stream, grad_src(f), (int)p->n, f->x_cur,
                      f->x_prev, f->scal, f->prm, t, f->dlt, p->part);
   hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->part, grid, fos::TRIAL_W, f->out5);
   LAUNCH_CHECK();
@@ -1910,10 +1947,10 @@ int fos_fista_trial_batch(fos_fista* f, double t, double eta, int nv, double* ou
   if (rc) return rc;
   const int grid = grid_1d(p->n_pad, 256, 64);
   if (p->dtype == FOS_BF16)
-    hipLaunchKernelGGL(fos::fista_trial_batch_bf16_kernel, dim3(grid), dim3(256), 0, p->stream, p->gbuf, (int)p->n,
+    hipLaunchKernelGGL(fos::fista_trial_batch_bf16_kernel, dim3(grid), dim3(256), 0, p->stream, grad_src(f), (int)p->n,
                        (int)p->n_pad, f->x_cur, f->x_prev, f->scal, f->prm, t, eta, nv, (unsigned short*)p->xp, p->part);
   else
-    hipLaunchKernelGGL(fos::fista_trial_batch_kernel, dim3(grid), dim3(256), 0, p->stream, p->gbuf, (int)p->n,
+    hipLaunchKernelGGL(fos::fista_trial_batch_kernel, dim3(grid), dim3(256), 0, p->stream, grad_src(f), (int)p->n,
                        (int)p->n_pad, f->x_cur, f->x_prev, f->scal, f->prm, t, eta, nv, p->xp, p->part);
   hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->part, grid, fos::BT_W, p->bt_out);
   LAUNCH_CHECK();

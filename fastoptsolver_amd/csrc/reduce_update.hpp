@@ -72,6 +72,14 @@ __device__ inline unsigned short f32_to_bf16_rn(float f) {
   return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);      // finite inputs only (differences of iterates)
 }
 __device__ inline float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+// Where a kernel takes the reduced gradient from: the fp32 buffer of the fp32 pass, or (precise mode: backtracking runs,
+// fos_fista_set_precise) the n doubles the fp64-accumulating pass left.
+struct GradSrc {
+  const float* f32;
+  const double* f64;
+};
+__device__ inline double grad_at(const GradSrc& g, int64_t i) { return g.f64 != nullptr ? g.f64[i] : (double)g.f32[i]; }
+
 // where the update kernel leaves y_{k+1} for the next pass over A
 enum : int { YOUT_VECTOR = 0, YOUT_XP = 1, YOUT_XQ = 2 };
 
@@ -200,7 +208,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 __global__ __launch_bounds__(256) void slab_reduce_dd_kernel(const double* __restrict__ slabs, int nslabs, int n,
                                                             int64_t stride, const double* __restrict__ rr_part, int n_rr,
                                                             double alpha2, const double* __restrict__ y,
-                                                            double* __restrict__ out) {
+                                                            double* __restrict__ out, const int* stopped = nullptr) {
+  if (stopped != nullptr && *stopped != 0) return;
   __shared__ double lds[4][128];
   const int pair = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int col = blockIdx.x * 128 + 2 * pair;
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(256) void slab_reduce_dd_kernel(const double* __res
 // ---------------------------------------------------------------------------------------------------------
 template <bool FROM_SLABS, bool VEC>
 __device__ inline void fista_update_body(const float* __restrict__ slabs, int nslabs,
-                                                          const float* __restrict__ gbuf, int n,
+                                                          GradSrc gsrc, int n,
                                                           double* __restrict__ x_cur, double* __restrict__ x_prev,
                                                           const FistaScalars* __restrict__ scal, FistaParams prm,
                                                           double* __restrict__ part, int host_beta, double beta_val,
@@ -255,7 +264,7 @@ __device__ inline void fista_update_body(const float* __restrict__ slabs, int ns
   __shared__ double dl[4 * 4];
   const int col0 = blockIdx.x * RCOLS;
   const double beta = host_beta ? beta_val : scal->beta;
-  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  double g[4] = {0.0, 0.0, 0.0, 0.0};
   int col, cnt = 0;
   bool owner;
   if constexpr (VEC) {
@@ -266,14 +275,14 @@ __device__ inline void fista_update_body(const float* __restrict__ slabs, int ns
       const f32x4 tot = reduce_slab_block(slabs, nslabs, n, col0, lds, slab_stride);
       g[0] = tot.x; g[1] = tot.y; g[2] = tot.z; g[3] = tot.w;
     } else if (owner) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(gbuf + col);
-      g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = col + e < n ? grad_at(gsrc, col + e) : 0.0;
     }
     cnt = owner ? (n - col < 4 ? n - col : 4) : 0;      // ragged n (padded slab rows): the last quad is partial
   } else {
     col = col0 + threadIdx.x;
     owner = (threadIdx.x < RCOLS) && (col < n);
-    if (owner) g[0] = FROM_SLABS ? reduce_slab_scalar(slabs, nslabs, n, col) : gbuf[col];
+    if (owner) g[0] = FROM_SLABS ? (double)reduce_slab_scalar(slabs, nslabs, n, col) : grad_at(gsrc, col);
     cnt = owner ? 1 : 0;
   }
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -282,7 +291,7 @@ __device__ inline void fista_update_body(const float* __restrict__ slabs, int ns
   for (int e = 0; e < cnt; ++e) {
     const double xc = x_cur[col + e], xp = x_prev[col + e];
     const double y = form_y(xc, xp, beta);
-    double gf = (double)g[e];
+    double gf = g[e];
     if (prm.prox_kind == PROX_L1 && prm.alpha2 > 0.0) gf += prm.alpha2 * y;
     const double v = y - prm.tau * gf;
     double xn = prm.alpha1 > 0.0 ? soft_threshold(v, thr) : v;
@@ -323,7 +332,7 @@ __device__ inline void fista_update_body(const float* __restrict__ slabs, int ns
 
 template <bool FROM_SLABS, bool VEC>
 __global__ __launch_bounds__(256) void fista_update_kernel(const float* __restrict__ slabs, int nslabs,
-                                                          const float* __restrict__ gbuf, int n,
+                                                          GradSrc gsrc, int n,
                                                           double* __restrict__ x_cur, double* __restrict__ x_prev,
                                                           const FistaScalars* __restrict__ scal, FistaParams prm,
                                                           double* __restrict__ part, int host_beta, double beta_val,
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(256) void fista_update_kernel(const float* __restri
                                                           float* __restrict__ y_next = nullptr, double beta_next = 0.0,
                                                           int64_t slab_stride = 0, int y_mode = YOUT_VECTOR,
                                                           int y_slot = 0) {
-  fista_update_body<FROM_SLABS, VEC>(slabs, nslabs, gbuf, n, x_cur, x_prev, scal, prm, part, host_beta, beta_val, x_hist,
+  fista_update_body<FROM_SLABS, VEC>(slabs, nslabs, gsrc, n, x_cur, x_prev, scal, prm, part, host_beta, beta_val, x_hist,
                                      y_next, beta_next, slab_stride, y_mode, y_slot);
 }
 
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(256) void fista_update_multi_kernel(const float* __
   const int v = blockIdx.y;
   FistaParams prm = prm0;                       // mode / prox kind / delta are common to the path; weights and steps are not
   prm.alpha1 = mu.alpha1[v]; prm.alpha2 = mu.alpha2[v]; prm.tau = mu.tau[v];
-  fista_update_body<true, true>(slabs + (int64_t)v * n, nslabs, nullptr, n, mu.x_cur[v], mu.x_prev[v], mu.scal[v], prm,
+  fista_update_body<true, true>(slabs + (int64_t)v * n, nslabs, GradSrc{nullptr, nullptr}, n, mu.x_cur[v], mu.x_prev[v], mu.scal[v], prm,
                                 mu.part[v], 1, mu.beta[v], nullptr, y_block, mu.beta_next[v], (int64_t)BT_NV * n, y_mode, v);
 }
 
@@ -438,7 +447,7 @@ __global__ void fista_init_scalars_kernel(FistaScalars* __restrict__ scal) {
 // Gradient-norm stop (iterative_solvers.py:179: `if tol > 0 and ||grad|| < tol: break`, checked BEFORE the update, grad of
 // the smooth part at y_k incl. alpha2*y) on the device, so that fista(tol > 0) stays enqueue-only: one workgroup reads the
 // reduced gradient in gbuf and raises the stop flag; the update and finalize kernels behind it are then no-ops.
-__global__ __launch_bounds__(1024) void grad_norm_stop_kernel(const float* __restrict__ gbuf, int n,
+__global__ __launch_bounds__(1024) void grad_norm_stop_kernel(GradSrc gsrc, int n,
                                                              const double* __restrict__ x_cur,
                                                              const double* __restrict__ x_prev,
                                                              FistaScalars* __restrict__ scal, FistaParams prm) {
@@ -447,7 +456,7 @@ __global__ __launch_bounds__(1024) void grad_norm_stop_kernel(const float* __res
   const double beta = scal->beta;
   double acc = 0.0;
   for (int i = threadIdx.x; i < n; i += 1024) {
-    double gf = (double)gbuf[i];
+    double gf = grad_at(gsrc, i);
     if (prm.prox_kind == PROX_L1 && prm.alpha2 > 0.0) gf += prm.alpha2 * form_y(x_cur[i], x_prev[i], beta);
     acc += gf * gf;
   }
@@ -541,7 +550,7 @@ __global__ __launch_bounds__(64) void history_fold_kernel(const double* __restri
 // out per workgroup: { grad.dlt, ||dlt||^2, #(dlt != 0), ||grad||^2, ||y||^2 }, grad including alpha2*y.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int TRIAL_W = 5;
-__global__ __launch_bounds__(256) void fista_trial_kernel(const float* __restrict__ gbuf, int n,
+__global__ __launch_bounds__(256) void fista_trial_kernel(GradSrc gsrc, int n,
                                                          const double* __restrict__ x_cur,
                                                          const double* __restrict__ x_prev,
                                                          const FistaScalars* __restrict__ scal, FistaParams prm,
@@ -554,7 +563,7 @@ __global__ __launch_bounds__(256) void fista_trial_kernel(const float* __restric
   double acc[TRIAL_W] = {0.0, 0.0, 0.0, 0.0, 0.0};
   for (int col = blockIdx.x * 256 + threadIdx.x; col < n; col += gridDim.x * 256) {
     const double y = form_y(x_cur[col], x_prev[col], beta);
-    double gf = (double)gbuf[col];
+    double gf = grad_at(gsrc, col);
     if (prm.prox_kind == PROX_L1 && prm.alpha2 > 0.0) gf += prm.alpha2 * y;
     const double v = y - t_trial * gf;
     double xt = prm.alpha1 > 0.0 ? soft_threshold(v, thr) : v;

@@ -128,18 +128,20 @@ _BATCH = 16      # candidate steps decided per pass over A (MFMA N dimension)
 _HISTORY_CHUNK_BYTES = 256 << 20   # device-resident x history is read back in chunks of at most this size
 
 
-def _armijo_accepts(tr, t_k, smooth_a2):
+def _armijo_accepts(tr, t_k, smooth_a2, grad_eps=8.0 * _EPS32):
     """g(x_tmp) <= g(y) + C*grad.dlt  <=>  (1-C)*grad.dlt + 0.5||A dlt||^2 + 0.5*a2*||dlt||^2 <= 0  (g quadratic).
 
     Resolution of the test: (a) the reference compares two float64 evaluations of g, so differences below
-    eps64*g(y) read as "equal" there (and x_tmp == y ends its loop); (b) our gradient comes from an fp32 pass over
-    A, so grad.dlt is only known to ~eps32*||grad||*||dlt||; (c) a trial step shorter than t*eps32*||grad|| lies
-    inside the noise ball of y_k: its direction is rounding noise, the decision meaningless and the step harmless
-    - the fp32-gradient counterpart of the reference's exact "x_tmp == y" exit."""
+    eps64*g(y) read as "equal" there (and x_tmp == y ends its loop); (b) grad.dlt is only known to
+    ~grad_eps*||grad||*||dlt||, where grad_eps is the relative resolution of the gradient pass; (c) a trial step
+    shorter than t*grad_eps*||grad|| lies inside the noise ball of y_k: its direction is rounding noise, the
+    decision meaningless and the step harmless - the counterpart of the reference's exact "x_tmp == y" exit.
+    grad_eps: 8*eps32 for the fp32 pass; 64*eps64 in precise mode (fos_fista_set_precise: fp64-accumulating pass at the
+    unrounded y_k, what fista(backtracking=True) runs), where (b) and (c) shrink to the reference's own rounding level."""
     excess = (1.0 - C) * tr["gd"] + 0.5 * tr["q"] + 0.5 * smooth_a2 * tr["dd"]
     g_y = 0.5 * tr["rr_y"] + 0.5 * smooth_a2 * tr["y2"]
-    noise = max(_EPS64 * g_y, 8.0 * _EPS32 * math.sqrt(tr["gnorm2"] * tr["dd"]))
-    in_noise_ball = tr["dd"] <= (8.0 * _EPS32 * t_k) ** 2 * tr["gnorm2"]
+    noise = max(_EPS64 * g_y, grad_eps * math.sqrt(tr["gnorm2"] * tr["dd"]))
+    in_noise_ball = tr["dd"] <= (grad_eps * t_k) ** 2 * tr["gnorm2"]
     return tr["nnz"] == 0 or excess <= noise or in_noise_ball
 
 
@@ -165,6 +167,12 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
     gtimer = getattr(st, "make_timer", _EventTimer)(grad_call_times)     # stand-in states bring a host timer
     smooth_a2 = alpha2 if (prox_kind == _lib.PROX_L1 and alpha2 > 0) else 0.0
     use_batch = batch_trials
+    # Backtracking decides on a cancelling sum (grad.dlt): take the gradient from the fp64-accumulating pass then
+    # (not in split-form sharding, where the fp32 gbuf is what travels through torch.distributed)
+    grad_eps = 8.0 * _EPS32
+    if backtracking and reducer is None and hasattr(st, "set_precise"):
+        st.set_precise(True)
+        grad_eps = 64.0 * _EPS64
 
     if not host_driven:
         stops_possible = tol > 0.0 or tol_ratio > 0.0
@@ -282,7 +290,7 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
                         tr["q"] = q
                         tr["rr_y"] = reducer.rr_global()
                 for tr in rows:
-                    if _armijo_accepts(tr, t_k, smooth_a2):
+                    if _armijo_accepts(tr, t_k, smooth_a2, grad_eps):
                         accepted = True
                         break
                     t_k *= eta                                 # ref:195

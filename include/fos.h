@@ -181,6 +181,12 @@ int fos_fista_destroy(fos_fista* f);
  * costs 1e-4 of parity on ill-conditioned data).  y_k is rounded once to fp32 for the pass over A. */
 int fos_fista_reset(fos_fista* f, const fos_fista_params* prm, const double* x0);
 int fos_fista_set_tau(fos_fista* f, double tau);
+/* Precise mode for the split form (fos_fista_grad / _trial / _trial_batch / _update): the gradient comes from the
+ * fp64-accumulating pass at the UNROUNDED y_k (the kernel of fos_gemv_pair_dd), so the terms of the Armijo comparison
+ * :191 - above all the cancelling sum grad.(x_tmp - y) - are fp64-accurate and the search takes the reference's decisions
+ * wherever those are decidable at all.  The pass costs 5-25 % more than the fp32 one; fista(backtracking=True) turns it
+ * on.  Plain fos_fista_run is unaffected. */
+int fos_fista_set_precise(fos_fista* f, int on);
 /* Enqueue `iters` full iterations (gradient, prox, momentum, restart and stop logic all on the device;
  * no host round trip).  Iterations after a device-side stop are no-ops.  :170-242, :289-342 */
 int fos_fista_run(fos_fista* f, int iters);
