@@ -1649,7 +1649,7 @@ static int run_multi_mfma(fos_fista* const* fs, int nv, int iters) {
     // - ~3000 rows at n = 8192 - would need a split-K product 1; see DESIGN.md "Multi-lambda".)
     const int64_t rows = 256 * (int64_t)p->ncu;
     p->panel_rows = std::min<int64_t>(rows, (p->m + 255) / 256 * 256);
-    const int64_t strips = (p->n + fos::GB_COLS - 1) / fos::GB_COLS;
+    const int64_t strips = (p->n + (is_bf16 ? fos::GQ_COLS : fos::GB_COLS) - 1) / (is_bf16 ? fos::GQ_COLS : fos::GB_COLS);
     int64_t splits = std::max<int64_t>(1, (2 * (int64_t)p->ncu + strips - 1) / strips);
     splits = std::min<int64_t>(splits, std::max<int64_t>(1, p->panel_rows / 256));
     p->gram_rows_per_split = ((p->panel_rows + splits - 1) / splits + fos::GB_ROWS - 1) / fos::GB_ROWS * fos::GB_ROWS;
@@ -1674,7 +1674,7 @@ static int run_multi_mfma(fos_fista* const* fs, int nv, int iters) {
     f->plain_count = 0;
   }
   const size_t psz = (size_t)fs[0]->nupd * 4;
-  const int64_t strips = (p->n + fos::GB_COLS - 1) / fos::GB_COLS;
+  const int64_t strips = (p->n + (is_bf16 ? fos::GQ_COLS : fos::GB_COLS) - 1) / (is_bf16 ? fos::GQ_COLS : fos::GB_COLS);
   // one update launch for all state machines when they differ in weights and steps only (a regularisation path does)
   bool same_family = true;
   for (int v = 1; v < nv; ++v) {
@@ -1692,8 +1692,14 @@ static int run_multi_mfma(fos_fista* const* fs, int nv, int iters) {
 #define FOS_GRAM(T, ACC)                                                                                                  \
   hipLaunchKernelGGL((fos::gram_batch_mfma_kernel<T, ACC>), grid, dim3(fos::GB_THREADS), 0, p->stream, (const T*)Ap, p->lda, \
                      rows, (int)p->n, p->rbuf16, p->gram_rows_per_split, p->slabs16, p->n)
-      if (is_bf16) { if (panel) FOS_GRAM(fos::bf16_t, true); else FOS_GRAM(fos::bf16_t, false); }
-      else { if (panel) FOS_GRAM(float, true); else FOS_GRAM(float, false); }
+      if (is_bf16) {
+        if (panel)
+          hipLaunchKernelGGL(fos::gram_batch_mfma_bf16_kernel<true>, grid, dim3(fos::GB_THREADS), 0, p->stream,
+                             (const fos::bf16_t*)Ap, p->lda, rows, (int)p->n, p->rbuf16, p->gram_rows_per_split, p->slabs16, p->n);
+        else
+          hipLaunchKernelGGL(fos::gram_batch_mfma_bf16_kernel<false>, grid, dim3(fos::GB_THREADS), 0, p->stream,
+                             (const fos::bf16_t*)Ap, p->lda, rows, (int)p->n, p->rbuf16, p->gram_rows_per_split, p->slabs16, p->n);
+      } else { if (panel) FOS_GRAM(float, true); else FOS_GRAM(float, false); }
 #undef FOS_GRAM
       LAUNCH_CHECK();
     }
