@@ -14,7 +14,7 @@
 // 64 x 64 tiles of A through LDS exactly like product 1 (coalesced 256-byte row segments, two register sets, straight-
 // line pair loop) and converts bf16 storage to fp32 on the way in, so one kernel serves both element types: at 16
 // right-hand sides the fp32 matrix pipe needs 32 flop per element, 40 % of its rate at the fp32 stream and 80 % at the
-// bf16 stream (a bf16-native form with transposed LDS reads is the known next step for config 5).
+// bf16 stream (bf16 storage has its own product-2 kernel below, natively on the bf16 pipe).
 // Slabs: slabs[split][lambda][n_stride]; panel 0 writes, later panels add (kernels of one stream: fixed order).
 #pragma once
 #include "batch_trial.hpp"
