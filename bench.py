@@ -143,18 +143,19 @@ def run_workload(name, args, rank, world, device, steps, warmup, want_cpu, dist)
     # the kernels' own stream - K2 -> slab reduce -> ncclAllReduce(n + 1 floats) -> prox + momentum, `k` iterations
     # enqueued without a host step (the gloo rehearsal keeps the split form driven from Python).
     comm = None
-    if world > 1 and args.backend == "nccl":
+    transport = os.environ.get("FOS_COMM_TRANSPORT", "rccl")    # "mesh": the one-shot full-mesh kernel (any backend)
+    if world > 1 and (args.backend == "nccl" or transport == "mesh"):
         try:
-            comm = fd.Comm(dist.group.WORLD)
+            comm = fd.Comm(dist.group.WORLD, transport=transport)
             ok = 1.0
         except Exception as exc:                 # e.g. no loadable RCCL for dlopen: fall back to the split form, loudly
             log(f"[rank {rank}] fos_comm unavailable ({exc}); falling back to torch.distributed all-reduce")
             ok = 0.0
-        flag = torch.tensor([ok], device=device)
+        flag = torch.tensor([ok], device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # all ranks take the same path
         if float(flag.item()) < 1.0:
             comm = None
-    args.comm_mode = "c-abi" if comm is not None else ("torch" if world > 1 else "none")
+    args.comm_mode = ("c-abi/" + transport) if comm is not None else ("torch" if world > 1 else "none")
     eng = fd.HipShardEngine(A, b, comm=comm, group=dist.group.WORLD if world > 1 else None)
     matvec_prob = fos.prepare(A, None)                       # same A, b = 0: power iteration / A^T b
     if comm is not None:
@@ -365,8 +366,9 @@ def main():
                             f"rows sharded over {world} GPU(s), alpha1={res['alpha1']:.4g}, alpha2={res['alpha2']}",
                 "m": cfg["m"], "n": cfg["n"], "rows_per_gpu": res["rows_per_gpu"],
                 "sharding": f"rows/{world}" if world > 1 else "none",
-                "collective": ("ncclAllReduce(SUM) of n+1 fp32 per iteration, enqueued by libfos_hip.so on the kernels' stream"
-                               if getattr(args, "comm_mode", "") == "c-abi" else
+                "collective": ("all-reduce(SUM) of n+1 fp32 per iteration, enqueued by libfos_hip.so on the kernels' stream ("
+                               + getattr(args, "comm_mode", "") + ")"
+                               if getattr(args, "comm_mode", "").startswith("c-abi") else
                                ("torch.distributed all-reduce of n+1 fp32 per iteration (split form)" if world > 1 else "none")),
                 "kernel_plan": res["plan"],
                 "iterate_state": "fp64 on device; y rounded once to fp32 for the single pass over A",
