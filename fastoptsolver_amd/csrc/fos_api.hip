@@ -1704,6 +1704,8 @@ static int run_multi_mfma(fos_fista* const* fs, int nv, int iters) {
       LAUNCH_CHECK();
     }
     if ((rc = prof_mark(p, false))) return rc;
+    // row-sharded problem: the 16 partial gradients (all row splits) are summed over the ranks before the updates
+    if ((rc = reduce_across(p, p->slabs16, (size_t)p->gram_splits * fos::BT_NV * p->n, false))) return rc;
     if (same_family) {                           // one launch updates all state machines
       fos::MultiUpdate mu{};
       for (int v = 0; v < nv; ++v) {
@@ -1756,11 +1758,12 @@ int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters) {
   fos_problem* p = fs[0]->p;
   bool all_plain = true;
   for (int v = 0; v < nv; ++v) all_plain = all_plain && plain_run(fs[v]);
-  const bool streaming = p->path == 0 && !p->tall && !p->colblock && !p->comm && !p->resident && all_plain;
-  MultiLaunch fn = (streaming && p->dtype == FOS_F32 && p->entry != &kWideF32) ? find_multi(p->n, nv) : nullptr;
+  const bool streaming = p->path == 0 && !p->tall && !p->colblock && !p->resident && all_plain;
+  // (a sharded problem takes the matrix-core pass for any number of weights: its 16 gradients are one 16 x n all-reduce)
+  MultiLaunch fn = (streaming && !p->comm && p->dtype == FOS_F32 && p->entry != &kWideF32) ? find_multi(p->n, nv) : nullptr;
   // the two-product pass costs about two single-vector passes per iteration whatever the number of weights: it pays
   // from three weights on (profiles/r02_multilambda.md); two weights without a VALU multi-vector kernel run one by one
-  if (!fn && streaming && p->entry != &kWideF32 && nv >= 3) {
+  if (!fn && streaming && p->entry != &kWideF32 && (nv >= 3 || p->comm)) {
     if (iters == 0) return FOS_OK;
     return run_multi_mfma(fs, nv, iters);          // 5..16 weights, n up to 16384, fp32 and bf16
   }

@@ -517,7 +517,8 @@ def fista_delta(A, b, reg_type: str, alpha1: float, alpha2: float, delta: float,
 # ---------------------------------------------------------------------
 # Regularisation path (extension)
 # ---------------------------------------------------------------------
-def fista_path(A, b, alphas, t_init_factor: float = 1.0, max_iter: int = 500, *, delta=None, L=None, dtype=None):
+def fista_path(A, b, alphas, t_init_factor: float = 1.0, max_iter: int = 500, *, delta=None, L=None, dtype=None,
+               comm=None):
     """Solve the same (A, b) for several regularisation weights at once.
 
     ``alphas`` is a sequence of ``(alpha1, alpha2)`` pairs.  The result is the list of solutions that
@@ -530,8 +531,8 @@ def fista_path(A, b, alphas, t_init_factor: float = 1.0, max_iter: int = 500, *,
     reset_metrics()
     if delta is not None:
         assert delta > 2, "In FISTA-Δ, delta must be > 2 for convergence (course requirement)"
-    prob = _core.as_problem(A, b, dtype)
-    like = prob.like
+    prob, _ = _sharded_problem(A, b, dtype, comm, None)      # comm: A, b are this rank's rows (matrix-core pass, one
+    like = prob.like                                         # all-reduce of the 16 gradients per iteration)
     L_val = estimate_lipschitz(prob) if L is None else float(L)
     mode = _lib.MODE_FISTA if delta is None else _lib.MODE_DELTA
     handles = []

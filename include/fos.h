@@ -215,8 +215,10 @@ int fos_fista_run_history(fos_fista* f, int iters, double* x_hist, double* hist,
  * from HBM once per iteration for all of them.  Otherwise (up to 16 weights, fp32 and bf16 storage, any streaming shape):
  * two GEMM-shaped products per iteration on the matrix cores for all weights together, R = A Y - b (v_mfma_f32_16x16x4_f32
  * / v_mfma_f32_16x16x32_bf16) and G = A^T R (csrc/gram_batch.hpp).  Results equal running each handle with
- * fos_fista_run (1e-6).  FOS_ERR_UNSUPPORTED when the shape has no such kernel (two-pass path, n <= 64, n > 16384 fp32,
- * sharded problems) or a handle needs data-dependent control: the caller then runs the handles one by one.
+ * fos_fista_run (1e-6).  A row-sharded problem (fos_problem_set_comm) takes the matrix-core pass for any number of
+ * weights: the 16 partial gradients are summed over the ranks in ONE all-reduce per iteration.  FOS_ERR_UNSUPPORTED when
+ * the shape has no such kernel (two-pass path, n <= 64, n > 16384 fp32) or a handle needs data-dependent control: the
+ * caller then runs the handles one by one.
  * SURVEY.md 8(f) rank 3. */
 int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters);
 /* Split form for host-driven control (grad-norm stop :179, backtracking :183-197, sharded runs):

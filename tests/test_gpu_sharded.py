@@ -255,6 +255,13 @@ def _mesh_worker(rank, world, port, out_dir):
     s = fos.LBFGSSolver("ridge", 0.0, a2).fit(As, bs, comm=comm)
     out["xl"], out["nfev"] = np.asarray(s.x_), np.asarray(s.nfev_)
     comm.check()
+    # (3) the multi-lambda pass on a row-sharded problem: 16 gradients, one all-reduce of 16 x n floats per iteration
+    big = fd.Comm(dist.group.WORLD, transport="mesh", cap_bytes=8 << 20)
+    lam = float(np.max(np.abs(A.T @ b)))
+    alphas = [(lam * 0.4 * 0.7 ** i, 0.5 if i % 3 == 1 else 0.0) for i in range(6)]
+    xs = fos.fista_path(As, bs, alphas, max_iter=25, L=L, comm=big)
+    out["xpath"] = np.stack([np.asarray(x) for x in xs])
+    big.check()
     np.savez(os.path.join(out_dir, f"m{rank}.npz"), **out)
     dist.barrier()
     dist.destroy_process_group()
@@ -281,3 +288,7 @@ def test_one_shot_mesh_allreduce_two_processes(tmp_path):
     assert _data.rel(r0["xbt"], x_ref) < TOL and np.allclose(r0["objbt"], h_ref["obj"], rtol=TOL)
     ref = orc.LBFGSSolver("ridge", 0.0, a2).fit(A, b)
     assert _data.rel(r0["xl"], ref.x_) < TOL and int(r0["nfev"]) == ref.nfev_
+    lam = float(np.max(np.abs(A.T @ b)))
+    for i in range(6):
+        a1p, a2p = lam * 0.4 * 0.7 ** i, (0.5 if i % 3 == 1 else 0.0)
+        assert _data.rel(r0["xpath"][i], orc.fista(A, b, "elasticnet", a1p, a2p, max_iter=25, L=L)) < TOL, i
