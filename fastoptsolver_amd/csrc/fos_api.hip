@@ -750,7 +750,8 @@ int ensure_dd(fos_problem* p) {
         if (c.dtype == p->dtype && (int64_t)c.threads * c.k * epc_of(p->dtype) >= p->n) { e = &c; break; }
     if (e) {
       p->dd_entry = e;
-      int nwg = p->ncu * (e->threads >= 512 ? 1 : e->threads == 256 ? (e->k <= 2 ? 2 : 1) : 1024 / e->threads);
+      // fp64 form: two workgroups per CU for every 256-thread geometry (they hold 2 waves per SIMD at most 256 VGPRs each)
+      int nwg = p->ncu * (e->threads >= 512 ? 1 : e->threads == 256 ? 2 : 1024 / e->threads);
       const int64_t min_rows = 2 * (int64_t)e->r;
       if (p->m < (int64_t)nwg * min_rows) nwg = (int)std::max<int64_t>(1, p->m / min_rows);
       p->dd_rows_per_wg = (p->m + nwg - 1) / nwg;
