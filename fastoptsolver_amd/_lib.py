@@ -20,6 +20,19 @@ class FistaParams(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class LineSearchState(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("f0", "d0", "dtest", "width", "width1", "lo", "flo", "dlo", "hi", "fhi", "dhi",
+                                           "smin", "smax")] + [(k, C.c_int32) for k in ("stage1", "brackt", "status", "reserved")]
+
+
+class LbfgsResult(C.Structure):
+    _fields_ = [("f", C.c_double), ("gmax", C.c_double), ("nit", C.c_int32), ("nfev", C.c_int32), ("task", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+LS_FG, LS_CONVERGENCE, LS_WARNING, LS_ERROR = 0, 1, 2, 3
+
+
 class FistaStatus(C.Structure):
     _fields_ = [("t_prev", C.c_double), ("beta", C.c_double), ("this_step", C.c_double), ("prev_step", C.c_double),
                 ("ratio", C.c_double), ("rr", C.c_double), ("gnorm2", C.c_double), ("xnorm1", C.c_double),
@@ -90,6 +103,10 @@ SIGNATURES = {
     "fos_lbfgs_two_loop_dd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
     "fos_vec_stats_dd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "fos_vec_axpby_dd": (_i32, [_f64, _vp, _f64, _vp, _vp, _i64, _vp]),
+    "fos_linesearch_begin": (_f64, [C.POINTER(LineSearchState), _f64, _f64, _f64]),
+    "fos_linesearch_step": (_f64, [C.POINTER(LineSearchState), _f64, _f64, _f64]),
+    "fos_lbfgs_minimize": (_i32, [_vp, _f64, _i32, _f64, _vp, C.POINTER(_f64), _vp, C.POINTER(C.c_float), _i32,
+                                  C.POINTER(LbfgsResult)]),
 }
 
 _lib = None

@@ -18,6 +18,7 @@
 #include "gemv_tall.hpp"
 #include "gemv_wide.hpp"
 #include "gram_batch.hpp"
+#include "lbfgs_driver.hpp"
 #include "lbfgs_kernels.hpp"
 #include "reduce_update.hpp"
 #include "resident.hpp"
@@ -2060,6 +2061,167 @@ int fos_vec_axpby_dd(double a, const double* x, double b, const double* y, doubl
                      x, b, b != 0.0 ? y : nullptr, out, n);
   LAUNCH_CHECK();
   return FOS_OK;
+}
+
+double fos_linesearch_begin(fos_linesearch* ls, double stp, double f0, double d0) {
+  return ls ? fos_ls_begin_impl(ls, stp, f0, d0) : stp;
+}
+double fos_linesearch_step(fos_linesearch* ls, double stp, double f, double d) {
+  return ls ? fos_ls_step_impl(ls, stp, f, d) : stp;
+}
+
+namespace {
+// device + pinned workspace of one fos_lbfgs_minimize call, released on every exit path
+struct LbfgsWork {
+  double *g = nullptr, *g_old = nullptr, *d = nullptr, *x_old = nullptr, *S = nullptr, *Y = nullptr, *stats = nullptr;
+  double* host = nullptr;              // pinned: 8 doubles
+  std::vector<hipEvent_t> ev;
+  ~LbfgsWork() {
+    void* bufs[] = {g, g_old, d, x_old, S, Y, stats};
+    for (void* q : bufs)
+      if (q) (void)hipFree(q);
+    if (host) (void)hipHostFree(host);
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  }
+};
+}  // namespace
+
+int fos_lbfgs_minimize(fos_problem* p, double alpha2, int max_iter, double pgtol, double* x, double* hist,
+                       double* iterates, float* fg_ms, int fg_cap, fos_lbfgs_result* res) {
+  if (!p || !x || !res || max_iter < 0) return fail(FOS_ERR_ARG, "fos_lbfgs_minimize: bad argument");
+  constexpr int M = 10, MAXLS = 20;
+  constexpr double FACTR = 1e7, EPS = 2.220446049250313e-16;
+  const int64_t n = p->n;
+  const size_t nb = (size_t)n * sizeof(double);
+  hipStream_t st = p->stream;
+  LbfgsWork w;
+  HIP_TRY(hipMalloc(&w.g, nb + 8 * sizeof(double)));
+  HIP_TRY(hipMalloc(&w.g_old, nb + 8 * sizeof(double)));
+  HIP_TRY(hipMalloc(&w.d, nb));
+  HIP_TRY(hipMalloc(&w.x_old, nb));
+  HIP_TRY(hipMalloc(&w.S, nb * M));
+  HIP_TRY(hipMalloc(&w.Y, nb * M));
+  HIP_TRY(hipMalloc(&w.stats, 8 * sizeof(double)));
+  HIP_TRY(hipHostMalloc(&w.host, 8 * sizeof(double)));
+  const int ax_grid = grid_1d(n, 256, 1024);
+  int nfev = 0;
+  double xnorm1 = 0.0;
+
+  // host scalars of one evaluation: [x.x, g.d, d.d, max|g|, ||x||_1, ||r||^2]
+  auto read_stats = [&](const double* xv, const double* gv, const double* dv, bool with_rr) -> int {
+    hipLaunchKernelGGL((fos::vec_stats_kernel<double, double>), dim3(1), dim3(fos::LB_THREADS), 0, st, xv, gv, dv, n, w.stats);
+    LAUNCH_CHECK();
+    HIP_TRY(hipMemcpyAsync(w.host, w.stats, 5 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (with_rr) HIP_TRY(hipMemcpyAsync(w.host + 5, gv + n, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return FOS_OK;
+  };
+  // loss and gradient at xv (lbfgs.py:43-54), plus g.d for the line search when dv is given
+  auto fg = [&](const double* xv, double* gv, const double* dv, double* loss, double* gd, double* gmax) -> int {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (fg_ms && nfev < fg_cap) {
+      HIP_TRY(hipEventCreate(&e0));
+      w.ev.push_back(e0);
+      HIP_TRY(hipEventCreate(&e1));
+      w.ev.push_back(e1);
+      HIP_TRY(hipEventRecord(e0, st));
+    }
+    int rc = fos_gemv_pair_dd(p, xv, alpha2, gv);
+    if (rc) return rc;
+    if (e1) HIP_TRY(hipEventRecord(e1, st));
+    if ((rc = read_stats(xv, gv, dv, true))) return rc;
+    nfev += 1;
+    *loss = 0.5 * w.host[5] + 0.5 * alpha2 * w.host[0];
+    *gd = w.host[1];
+    *gmax = w.host[3];
+    xnorm1 = w.host[4];
+    return FOS_OK;
+  };
+  auto axpby = [&](double a, const double* xv, double b, const double* yv, double* out) {
+    hipLaunchKernelGGL(fos::vec_axpby_f64_kernel<double>, dim3(ax_grid), dim3(256), 0, st, a, xv, b, b != 0.0 ? yv : nullptr,
+                       out, n);
+  };
+  auto finish = [&](double f, double gmax, int nit, int task) -> int {
+    res->f = f; res->gmax = gmax; res->nit = nit; res->nfev = nfev; res->task = task; res->reserved = 0;
+    if (fg_ms) {
+      HIP_TRY(hipStreamSynchronize(st));
+      for (size_t i = 0; i + 1 < w.ev.size(); i += 2) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, w.ev[i], w.ev[i + 1]));
+        fg_ms[i / 2] = ms;
+      }
+    }
+    return FOS_OK;
+  };
+
+  double *g = w.g, *g_old = w.g_old;
+  int hist_n = 0, head = 0, nit = 0;
+  double f = 0.0, gd = 0.0, gmax = 0.0;
+  int rc = fg(x, g, nullptr, &f, &gd, &gmax);
+  if (rc) return rc;
+  if (gmax <= pgtol) return finish(f, gmax, 0, 0);
+  for (;;) {
+    // direction d = -H g (two-loop recursion over the stored pairs)
+    const bool vec = (n % 4 == 0);
+#define FOS_TL(NQ) hipLaunchKernelGGL((fos::lbfgs_two_loop_kernel<double, NQ>), dim3(1), dim3(fos::LB_THREADS), 0, st, \
+                                      (const double*)g, (const double*)w.S, (const double*)w.Y, hist_n, head, M, n, w.d)
+    if (vec && n <= 4096) FOS_TL(1);
+    else if (vec && n <= 8192) FOS_TL(2);
+    else if (vec && n <= 16384) FOS_TL(4);
+    else FOS_TL(0);
+#undef FOS_TL
+    LAUNCH_CHECK();
+    if ((rc = read_stats(nullptr, g, w.d, false))) return rc;
+    const double gd0 = w.host[1], dd = w.host[2];
+    if (gd0 >= 0.0) {                           // not a descent direction: drop the memory (L-BFGS-B info = -4)
+      if (hist_n == 0) return finish(f, gmax, nit, 3);
+      hist_n = 0; head = 0;
+      continue;
+    }
+    double stp = nit == 0 ? std::min(1.0 / std::sqrt(dd), 1e10) : 1.0;
+    HIP_TRY(hipMemcpyAsync(w.x_old, x, nb, hipMemcpyDeviceToDevice, st));
+    std::swap(g, g_old);                        // g_old holds the gradient at x_old; g receives the trial gradients
+    const double f_old = f, gmax_old = gmax;
+    fos_linesearch ls{};
+    stp = fos_ls_begin_impl(&ls, stp, f_old, gd0);
+    int evals = 0;
+    bool failed = false;
+    double gd1 = gd0, stp_used = stp;
+    for (;;) {
+      if (evals >= MAXLS) { failed = true; break; }
+      axpby(1.0, w.x_old, stp, w.d, x);         // x = stp*d + x_old, products and sum rounded separately (NumPy's)
+      LAUNCH_CHECK();
+      if ((rc = fg(x, g, w.d, &f, &gd1, &gmax))) return rc;
+      evals += 1;
+      stp_used = stp;
+      stp = fos_ls_step_impl(&ls, stp, f, gd1);
+      if (ls.status != FOS_LS_FG) break;
+    }
+    if (failed || ls.status == FOS_LS_ERROR) {
+      HIP_TRY(hipMemcpyAsync(x, w.x_old, nb, hipMemcpyDeviceToDevice, st));
+      std::swap(g, g_old);
+      f = f_old; gmax = gmax_old;
+      if (hist_n == 0) return finish(f, gmax, nit, 3);
+      hist_n = 0; head = 0;
+      continue;
+    }
+    stp = stp_used;
+    if (hist) { hist[2 * nit] = f; hist[2 * nit + 1] = xnorm1; }
+    if (iterates) HIP_TRY(hipMemcpyAsync(iterates + (size_t)nit * n, x, nb, hipMemcpyDeviceToDevice, st));
+    nit += 1;
+    if (nit >= max_iter) return finish(f, gmax, nit, 2);
+    if (gmax <= pgtol) return finish(f, gmax, nit, 0);
+    if ((f_old - f) <= EPS * FACTR * std::max(std::max(std::fabs(f_old), std::fabs(f)), 1.0)) return finish(f, gmax, nit, 1);
+    const double sy = (gd1 - gd0) * stp;
+    if (sy > EPS * (-gd0 * stp)) {              // keep the pair only if its curvature is positive
+      const int slot = (head + hist_n) % M;
+      if (hist_n == M) head = (head + 1) % M;
+      else hist_n += 1;
+      axpby(stp, w.d, 0.0, nullptr, w.S + (size_t)slot * n);             // s = stp * d
+      axpby(1.0, g, -1.0, g_old, w.Y + (size_t)slot * n);                // y = g - g_old
+      LAUNCH_CHECK();
+    }
+  }
 }
 
 int fos_vec_stats(const float* x, const float* g, const float* d, int64_t n, double* out5, void* stream) {

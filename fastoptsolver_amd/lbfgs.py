@@ -117,6 +117,35 @@ class LBFGSSolver:
         self.history_ = []
 
     # ------------------------------------------------------------------------------------------------------
+    _TASKS = ("CONVERGENCE: NORM_OF_PROJECTED_GRADIENT_<=_PGTOL", "CONVERGENCE: REL_REDUCTION_OF_F_<=_FACTR*EPSMCH",
+              "STOP: TOTAL NO. OF ITERATIONS REACHED LIMIT", "ABNORMAL_TERMINATION_IN_LNSRCH")
+
+    def _fit_native(self, ops):
+        """The whole iteration under the C ABI (fos_lbfgs_minimize: what SciPy's compiled optimiser is to lbfgs.py:64):
+        line search and memory logic in C++ on the host, every vector on the device, six scalars read per fg."""
+        import ctypes as C
+        prob, n = ops.prob, ops.n
+        a2 = float(self.alpha2) if self.reg_type in ("ridge", "elasticnet") else 0.0   # lbfgs.py:49-51
+        max_iter = int(self.max_iter)
+        x = ops.new_x()                                                              # lbfgs.py:63
+        hist = (C.c_double * max(2 * max_iter, 1))()
+        keep = max_iter * n * 8 <= (1 << 30)                  # iterates_ (an extension) only while they fit 1 GiB
+        iterates = torch.empty(max(max_iter, 1), n, dtype=torch.float64, device=ops.dev) if keep else None
+        cap = 21 * max_iter + 2
+        fg_ms = (C.c_float * cap)()
+        res = _lib.LbfgsResult()
+        with prob.ctx():
+            _lib.check(ops.lib.fos_lbfgs_minimize(prob.h, a2, max_iter, float(self.tol), _core.ptr(x), hist,
+                                                  _core.ptr(iterates), fg_ms, cap, C.byref(res)), "fos_lbfgs_minimize")
+        self.nit_, self.nfev_, self.task_ = int(res.nit), int(res.nfev), self._TASKS[res.task]
+        grad_call_times.extend(float(fg_ms[i]) * 1e-3 for i in range(min(self.nfev_, cap)))
+        l1 = self.reg_type in ("lasso", "elasticnet")
+        self.history_.extend(hist[2 * k] + (self.alpha1 * hist[2 * k + 1] if l1 else 0.0) for k in range(self.nit_))
+        self.iterates_ = [ops.to_caller(iterates[k]) for k in range(self.nit_)] if keep else []
+        self.x_ = ops.to_caller(x)                                                    # lbfgs.py:71
+        self.final_obj_ = float(res.f)                                                # lbfgs.py:72
+        return self
+
     def fit(self, A, b, *, group=None, comm=None, ops=None):
         """``group`` / ``comm``: A, b are THIS RANK's rows of a row-sharded problem; every ``fg`` all-reduces
         [partial gradient ; partial ||r||^2] (n + 1 doubles) once and all ranks take identical decisions on
@@ -125,6 +154,8 @@ class LBFGSSolver:
         backend): it runs here, between the kernels.  ``ops``: the vector/pass primitives (default: the HIP kernels;
         the gloo CPU test injects a stand-in)."""
         reset_metrics()
+        if ops is None and (group is None or dist.get_world_size(group) == 1):
+            return self._fit_native(_HipOps(A, b, comm))
         ops = ops if ops is not None else _HipOps(A, b, comm)
         sharded = comm is None and group is not None and dist.get_world_size(group) > 1
         a2 = float(self.alpha2) if self.reg_type in ("ridge", "elasticnet") else 0.0   # lbfgs.py:49-51

@@ -270,6 +270,37 @@ int fos_vec_stats_dd(const double* x, const double* g, const double* d, int64_t 
  * `stp * d + x_old`, `g - g_old`, `stp * d` (oracle lbfgs_minimize). */
 int fos_vec_axpby_dd(double a, const double* x, double b, const double* y, double* out, int64_t n, void* stream);
 
+/* ---- the optimiser itself: what scipy.optimize.fmin_l_bfgs_b is to lbfgs.py:64 --------------------------------------
+ * Moré–Thuente line search (MINPACK-2 dcsrch with L-BFGS-B's constants ftol 1e-3, gtol 0.9, xtol 0.1, stpmin 0,
+ * stpmax 1e10) in reverse communication: host scalars only, usable without a GPU.
+ *   stp = fos_linesearch_begin(&ls, stp0, f(0), f'(0));  loop: stp = fos_linesearch_step(&ls, stp, f(stp), f'(stp))
+ * until ls.status != FOS_LS_FG. */
+enum { FOS_LS_FG = 0, FOS_LS_CONVERGENCE = 1, FOS_LS_WARNING = 2, FOS_LS_ERROR = 3 };
+typedef struct fos_linesearch {
+  double f0, d0, dtest, width, width1;
+  double lo, flo, dlo, hi, fhi, dhi, smin, smax;
+  int32_t stage1, brackt, status, reserved;
+} fos_linesearch;
+double fos_linesearch_begin(fos_linesearch* ls, double stp, double f0, double d0);
+double fos_linesearch_step(fos_linesearch* ls, double stp, double f, double d);
+
+/* The whole unbounded L-BFGS-B iteration of lbfgs.py:63-70 (SciPy defaults m = 10, factr = 1e7, maxls = 20; maxiter and
+ * pgtol from the caller) as ONE call: fg = fos_gemv_pair_dd, direction = the fp64 two-loop kernel, the line search above
+ * on the host, all vectors fp64 on the device; the host reads 6 scalars per fg evaluation and nothing else.
+ *   x         device, n doubles: start point in, solution out                                   lbfgs.py:63, :71
+ *   hist      host, 2*max_iter doubles (nullable): after iteration k, hist[2k] = loss of fg at x_k, hist[2k+1] = ||x_k||_1
+ *             (the callback's compute_objective(x_k) = loss + alpha1*||x_k||_1 without an extra pass)   lbfgs.py:56-61
+ *   iterates  device, max_iter*n doubles (nullable): x_k after every iteration
+ *   fg_ms     host, fg_cap floats (nullable): device milliseconds of every fg evaluation (get_metrics)
+ * task: 0 |proj g| <= pgtol, 1 relative reduction of f <= factr*epsmch, 2 iteration limit, 3 abnormal termination in
+ * the line search.  Works on sharded problems (fos_problem_set_comm).  Synchronises. */
+typedef struct fos_lbfgs_result {
+  double f, gmax;
+  int32_t nit, nfev, task, reserved;
+} fos_lbfgs_result;
+int fos_lbfgs_minimize(fos_problem* p, double alpha2, int max_iter, double pgtol, double* x, double* hist,
+                       double* iterates, float* fg_ms, int fg_cap, fos_lbfgs_result* res);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,3 +51,32 @@ def test_rejects_ascent_direction():
     ls = LineSearch()
     ls.begin(1.0, 1.0, +0.5)
     assert ls.status.startswith("ERROR")
+
+
+def test_native_line_search_equals_the_python_one():
+    """The C++ search inside libfos_hip.so (fos_linesearch_*, what fos_lbfgs_minimize runs) step for step against the
+    Python restatement that is pinned to SciPy's DCSRCH above.  Host scalars only: runs without a GPU."""
+    import ctypes as C
+    from fastoptsolver_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(1)
+    names = {_lib.LS_FG: "FG", _lib.LS_CONVERGENCE: "CONVERGENCE", _lib.LS_WARNING: "WARNING", _lib.LS_ERROR: "ERROR"}
+    checked = 0
+    for trial in range(120):
+        phi, dphi = _functions(rng)
+        if dphi(0.0) >= 0:
+            continue
+        a1 = float(rng.choice([1.0, 0.01, 25.0]))
+        ls = LineSearch()
+        seq, status = _run(ls.begin, ls.step, lambda: ls.status, a1, phi, dphi)
+        st = _lib.LineSearchState()
+        seq_c, status_c = _run(lambda s, f, d: lib.fos_linesearch_begin(C.byref(st), s, f, d),
+                               lambda s, f, d: lib.fos_linesearch_step(C.byref(st), s, f, d),
+                               lambda: names[st.status], a1, phi, dphi)
+        assert seq_c == seq, trial                       # bit for bit: the same IEEE operations in the same order
+        assert status.startswith(status_c), (trial, status, status_c)
+        checked += 1
+    assert checked > 60
+    st = _lib.LineSearchState()
+    lib.fos_linesearch_begin(C.byref(st), 1.0, 1.0, 0.5)
+    assert st.status == _lib.LS_ERROR
