@@ -233,3 +233,35 @@ def test_random_shapes_and_layouts_gemv_pair(fos, seed):
     assert np.linalg.norm(g - g_ref) <= g_tol, (seed, m, n, pad, off, prob.plan())
     rr = prob.residual_objective(torch.as_tensor(y).cuda())[0]
     assert abs(rr - rr_ref) <= 5e-6 * rr_ref + 2.0 * r_norm * dr + dr * dr, (seed, m, n, pad, off, prob.plan())
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FOS_FUZZ_PATH_SEEDS", "16"))))
+def test_random_regularisation_paths(fos, seed):
+    """fista_path on random shapes / storage types / weight counts: the multi-vector VALU pass (<= 4 weights, fp32,
+    n <= 8192), the matrix-core pass (3..16 weights; partial tiles in rows and columns, several row splits), one-by-one
+    fall-backs (ragged n, n <= 64) - every solution against the oracle on the stored A."""
+    rng = np.random.default_rng(7000 + seed)
+    m = int(rng.choice([3, 64, 130, 257, 1000, 2049, 5000]))
+    n = int(rng.choice([8, 64, 72, 128, 264, 1000, 1024, 2056, 4096]))
+    kind = str(rng.choice(["f32", "f32", "bf16"]))
+    nlam = int(rng.choice([2, 3, 4, 5, 9, 16]))
+    iters = int(rng.integers(3, 20))
+    A = rng.standard_normal((m, n)).astype(np.float32)
+    At = torch.as_tensor(A).to(torch.bfloat16 if kind == "bf16" else torch.float32).cuda()
+    A64 = At.to(torch.float64).cpu().numpy()
+    b32 = rng.standard_normal(m).astype(np.float32)
+    b = b32.astype(np.float64)
+    lam = float(np.max(np.abs(A64.T @ b))) or 1.0
+    L = float(np.linalg.norm(A64, "fro") ** 2) or 1.0
+    alphas = [(lam * float(rng.choice([0.5, 0.1, 0.01])) * 0.8 ** i, float(rng.choice([0.0, 0.5]))) for i in range(nlam)]
+    delta = float(rng.choice([0.0, 0.0, 3.5]))
+    xs = fos.fista_path(fos.prepare(At, b32), None, alphas, max_iter=iters, L=L, **({"delta": delta} if delta else {}))
+    assert len(xs) == nlam
+    for (a1, a2), x in zip(alphas, xs):
+        if delta:
+            x_ref = orc.fista_delta(A64, b, "elasticnet", a1, a2, delta, max_iter=iters, L=L)
+        else:
+            x_ref = orc.fista(A64, b, "elasticnet", a1, a2, max_iter=iters, L=L)
+        x = x.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(x) else np.asarray(x)
+        den = float(np.linalg.norm(x_ref))
+        assert np.linalg.norm(x - x_ref) <= 1e-5 * den + 1e-12, (seed, m, n, kind, nlam, iters, a1, a2, delta)

@@ -632,6 +632,30 @@ def test_wide_rows(fos, m, n, kind):
             assert np.allclose(out[1]["obj"], ref[1]["obj"], rtol=TOL)
 
 
+def test_wide_rows_bf16_and_sharded_column_blocks(fos):
+    """bf16 rows beyond 16384 columns take the column-blocked passes too; with a communicator attached the blocks' slabs
+    go through the same slab reduction + all-reduce as any other plan."""
+    from fastoptsolver_amd import distributed as fd
+    rng = np.random.default_rng(9)
+    m, n = 150, 20000
+    A16 = torch.as_tensor(rng.standard_normal((m, n)).astype(np.float32)).to(torch.bfloat16).cuda()
+    A64 = A16.to(torch.float64).cpu().numpy()
+    b = rng.standard_normal(m).astype(np.float32)
+    y = rng.standard_normal(n).astype(np.float32)
+    prob = fos.prepare(A16, b, pad=False)
+    assert prob.plan()["colblock"] == 1 and prob.dtype == "bf16"
+    g_ref, rr_ref = orc.gram_gradient(A64, y.astype(np.float64), b.astype(np.float64), 0.2)
+    assert _data.rel(prob.gemv_pair(_dev(y), alpha2=0.2).cpu().numpy(), g_ref) < TOL
+    assert prob.residual_objective(_dev(y))[0] == pytest.approx(rr_ref, rel=TOL)
+    L = float(np.linalg.norm(A64, 2) ** 2)
+    x_ref = orc.fista(A64, b.astype(np.float64), "elasticnet", 3.0, 0.5, max_iter=15, L=L)
+    assert _data.rel(_np(fos.fista(prob, None, "elasticnet", 3.0, 0.5, max_iter=15, L=L)), x_ref) < TOL
+    comm = fd.Comm.solo()
+    x_c = fos.fista(A16, b, "elasticnet", 3.0, 0.5, max_iter=15, L=L, comm=comm, backtracking=True, t_init_factor=2.0)
+    x_bt = orc.fista(A64, b.astype(np.float64), "elasticnet", 3.0, 0.5, max_iter=15, L=L, backtracking=True, t_init_factor=2.0)
+    assert _data.rel(_np(x_c), x_bt) < TOL
+
+
 def test_armijo_constant_is_read_at_call_time(fos, monkeypatch):
     """iterative_solvers.C is a module global read inside the loop (reference :11, :191): patching it must bite."""
     from fastoptsolver_amd import iterative_solvers as its

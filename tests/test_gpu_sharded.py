@@ -267,6 +267,40 @@ def _mesh_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _mesh4_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fastoptsolver_amd import distributed as fd
+    comm = fd.Comm(dist.group.WORLD, transport="mesh", cap_bytes=1 << 20)
+    ok = True
+    for rnd in range(8):
+        for count, dt in ((7, torch.float32), (16385, torch.float32), (40000, torch.float64)):
+            g = torch.Generator(device="cuda").manual_seed(31 * rnd + count)
+            every = [torch.randn(count, device="cuda", dtype=dt, generator=g) for _ in range(world)]
+            mine = every[rank].clone()
+            comm.allreduce(mine)
+            want = every[0].clone()
+            for r in range(1, world):
+                want += every[r]
+            ok = ok and bool(torch.equal(mine, want))
+    comm.check()
+    np.savez(os.path.join(out_dir, f"q{rank}.npz"), ok=np.asarray(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_one_shot_mesh_allreduce_four_processes(tmp_path):
+    """Four ranks (four processes sharing the GPU): inbox rows, flag rows and the rank-order sum for P > 2."""
+    import torch.multiprocessing as mp
+    world = 4
+    mp.spawn(_mesh4_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(bool(np.load(tmp_path / f"q{r}.npz")["ok"]) for r in range(world))
+
+
 @pytest.mark.timeout(600)
 def test_one_shot_mesh_allreduce_two_processes(tmp_path):
     import torch.multiprocessing as mp
