@@ -200,8 +200,9 @@ void tallr_launch_dd(const void* A, int64_t lda, const float* b, int64_t m, int 
 #define TALLR(DT, T, LPR) \
   { DT, fos::TL_THREADS, LPR, 0, tallr_launch<T, LPR, true, false>, tallr_launch<T, LPR, false, false>, \
     tallr_launch<T, LPR, true, true>, tallr_launch_dd<T, LPR> }
-const MenuEntry kTallRowsF32[3] = {TALLR(FOS_F32, float, 4), TALLR(FOS_F32, float, 8), TALLR(FOS_F32, float, 16)};
-const MenuEntry kTallRowsBf16[2] = {TALLR(FOS_BF16, fos::bf16_t, 4), TALLR(FOS_BF16, fos::bf16_t, 8)};
+// (a row per 4 lanes - up to 4 chunks - measured slower than the row-per-thread form and is not instantiated)
+const MenuEntry kTallRowsF32[2] = {TALLR(FOS_F32, float, 8), TALLR(FOS_F32, float, 16)};
+const MenuEntry kTallRowsBf16[1] = {TALLR(FOS_BF16, fos::bf16_t, 8)};
 #undef TALLR
 // 33..64 columns: a row per quad of lanes (gemv_tall_quad_kernel)
 #define TALLQ(DT, T, VEC) \
@@ -230,8 +231,8 @@ const MenuEntry* tall_entry(int dtype, int64_t n, int64_t lda, const void* A) {
   // with 16-byte loads is the faster one (4000000 x 16: 72-76 % against 67-69 %, profiles/r02_sweep_wgs.log).
   if (n % epc == 0 && lda % epc == 0 && (reinterpret_cast<uintptr_t>(A) & 15u) == 0 && n / epc > 4) {
     const int chunks = (int)(n / epc);
-    if (dtype == FOS_F32) return &kTallRowsF32[chunks <= 8 ? 1 : 2];
-    return &kTallRowsBf16[1];
+    if (dtype == FOS_F32) return &kTallRowsF32[chunks <= 8 ? 0 : 1];
+    return &kTallRowsBf16[0];
   }
   const int idx = n <= 8 ? 0 : n <= 16 ? 1 : n <= 32 ? 2 : 3;
   const bool contiguous = (lda == n);
