@@ -345,6 +345,28 @@ class Fista:
             out["hist"] = hist[:k]
         return out
 
+    def run_backtracking(self, iters, eta, armijo_c, grad_eps):
+        """Enqueue `iters` backtracking iterations decided on the device (fos_fista_run_backtracking).  Returns
+        (ls_iters int32 tensor, tau_hist float64 tensor) - device tensors, valid for the completed iterations - or
+        None when this plan has no candidate pass (callers then drive the search from the host)."""
+        dev = self.prob.device
+        ls = torch.zeros(max(int(iters), 1), dtype=torch.int32, device=dev)
+        taus = torch.zeros(max(int(iters), 1), dtype=torch.float64, device=dev)
+        with self.prob.ctx():
+            rc = self.lib.fos_fista_run_backtracking(self.h, int(iters), float(eta), float(armijo_c), float(grad_eps),
+                                                     ptr(ls), ptr(taus))
+        if rc == -4:
+            return None
+        _lib.check(rc, "fos_fista_run_backtracking")
+        return ls, taus
+
+    def resume_after_stall(self):
+        """The device parked a search whose 16 candidates were all rejected: take the current step back to the host."""
+        tau = C.c_double()
+        with self.prob.ctx():
+            _lib.check(self.lib.fos_fista_resume_after_stall(self.h, C.byref(tau)), "fos_fista_resume_after_stall")
+        return float(tau.value)
+
     def grad(self, dual=False):
         """Gradient pass at y_k; dual=True also leaves ||A x_k - b||^2 in status().rr_x (same pass over A)."""
         with self.prob.ctx():

@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(HERE, "libfos_hip.so")
 FOS_F32, FOS_BF16 = 0, 1
 MODE_FISTA, MODE_DELTA, MODE_ISTA = 0, 1, 2
 PROX_L1, PROX_ENET = 0, 1
-STOP_NONE, STOP_STEP, STOP_RATIO, STOP_GRAD = 0, 1, 2, 3
+STOP_NONE, STOP_STEP, STOP_RATIO, STOP_GRAD, STOP_LS_STALL = 0, 1, 2, 3, 4
 PLAN_NO_RESIDENT, PLAN_NO_TALL, PLAN_NO_WIDE, PLAN_NO_COLBLOCK = 1, 2, 4, 8
 
 
@@ -36,7 +36,7 @@ LS_FG, LS_CONVERGENCE, LS_WARNING, LS_ERROR = 0, 1, 2, 3
 class FistaStatus(C.Structure):
     _fields_ = [("t_prev", C.c_double), ("beta", C.c_double), ("this_step", C.c_double), ("prev_step", C.c_double),
                 ("ratio", C.c_double), ("rr", C.c_double), ("gnorm2", C.c_double), ("xnorm1", C.c_double),
-                ("xnorm2", C.c_double), ("rr_x", C.c_double), ("k", C.c_int64), ("stopped", C.c_int32),
+                ("xnorm2", C.c_double), ("rr_x", C.c_double), ("tau", C.c_double), ("k", C.c_int64), ("stopped", C.c_int32),
                 ("restarts", C.c_int32)]
 
 
@@ -91,6 +91,8 @@ SIGNATURES = {
     "fos_fista_update": (_i32, [_vp]),
     "fos_fista_trial": (_i32, [_vp, _f64, _i32, C.POINTER(_f64)]),   # out8
     "fos_fista_trial_batch": (_i32, [_vp, _f64, _f64, _i32, C.POINTER(_f64)]),
+    "fos_fista_run_backtracking": (_i32, [_vp, _i32, _f64, _f64, _f64, _vp, _vp]),
+    "fos_fista_resume_after_stall": (_i32, [_vp, C.POINTER(_f64)]),
     "fos_fista_status_get": (_i32, [_vp, C.POINTER(FistaStatus)]),
     "fos_fista_get_x": (_i32, [_vp, _vp]),
     "fos_fista_x": (_vp, [_vp]),

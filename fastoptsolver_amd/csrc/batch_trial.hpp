@@ -42,8 +42,12 @@ __global__ __launch_bounds__(256) void fista_trial_batch_kernel(GradSrc gsrc, in
                                                                const double* __restrict__ x_prev,
                                                                const FistaScalars* __restrict__ scal, FistaParams prm,
                                                                double t0, double eta, int nv, float* __restrict__ xp,
-                                                               double* __restrict__ part) {
+                                                               double* __restrict__ part, int t_from_state = 0) {
   __shared__ double red[4][BT_W];
+  if (t_from_state) {                            // device-driven backtracking: the step lives in FistaScalars::tau
+    if (scal->stopped != 0) return;
+    t0 = scal->tau;
+  }
   const double beta = scal->beta;
   double gd[BT_NV], dd[BT_NV], nz[BT_NV];
 #pragma unroll
@@ -104,7 +108,9 @@ __global__ __launch_bounds__(BT_THREADS) void residual_batch_mfma_kernel(const f
                                                                         const float* __restrict__ xp,
                                                                         int64_t groups_per_wg,
                                                                         double* __restrict__ q_part,
-                                                                        float* __restrict__ rout = nullptr) {
+                                                                        float* __restrict__ rout = nullptr,
+                                                                        const int* __restrict__ stopped = nullptr) {
+  if (stopped != nullptr && *stopped != 0) return;          // parked pipeline (solver stopped / line search stalled)
   constexpr int ROWS = BT_ROWS * RB;              // RB 16-row blocks per wave share each candidate fragment read
   constexpr int A_LOADS = BT_A_LOADS * RB;
   __shared__ __attribute__((aligned(16))) float a_s[2][ROWS][BT_LDS_STRIDE];
@@ -249,8 +255,12 @@ __global__ __launch_bounds__(256) void fista_trial_batch_bf16_kernel(GradSrc gsr
                                                                     const FistaScalars* __restrict__ scal,
                                                                     FistaParams prm, double t0, double eta, int nv,
                                                                     unsigned short* __restrict__ xq,
-                                                                    double* __restrict__ part) {
+                                                                    double* __restrict__ part, int t_from_state = 0) {
   __shared__ double red[4][BT_W];
+  if (t_from_state) {
+    if (scal->stopped != 0) return;
+    t0 = scal->tau;
+  }
   const double beta = scal->beta;
   double gd[BT_NV], dd[BT_NV], nz[BT_NV];
 #pragma unroll
@@ -326,7 +336,8 @@ template <int RB, int COLS, bool STORE_R = false>
 __global__ __launch_bounds__(BT_THREADS) void residual_batch_mfma_bf16_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const float* __restrict__ b, int use_b, int64_t m, int n,
     const unsigned short* __restrict__ xq, int64_t groups_per_wg, double* __restrict__ q_part,
-    float* __restrict__ rout = nullptr) {
+    float* __restrict__ rout = nullptr, const int* __restrict__ stopped = nullptr) {
+  if (stopped != nullptr && *stopped != 0) return;
   constexpr int ROWS = 64 * RB;
   constexpr int STRIDE = COLS + 8;
   constexpr int CPR = COLS / 8;                               // 16-byte chunks per tile row

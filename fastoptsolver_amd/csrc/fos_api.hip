@@ -337,6 +337,7 @@ struct fos_fista {
   // precise mode (fos_fista_set_precise): the split-form gradient comes from the fp64-accumulating pass at the unrounded
   // fp64 y_k, so that the Armijo comparison g(x_tmp) <= g(y) + C grad.dlt is decided on fp64-accurate terms
   bool precise = false;
+  bool tau_on_device = false;        // FistaScalars::tau is authoritative (device-driven backtracking ran since the last set_tau / reset)
   double* gbuf64 = nullptr;          // n + 4 doubles: [gradient ; ||r||^2]
   double* out5 = nullptr;            // device
   int nupd = 0;                      // workgroups of the update kernel
@@ -625,14 +626,15 @@ int ensure_batch_workspace(fos_problem* p) {
 // <4,64> 170.4 us.  The 128-row tile halves the LDS re-reads of the candidate fragments per byte of A; the 64-row
 // tile is kept for short problems, where it gives twice as many workgroups.
 typedef void (*Bf16Batch)(const fos::bf16_t*, int64_t, const float*, int, int64_t, int, const unsigned short*, int64_t, double*,
-                          float*);
+                          float*, const int*);
 struct Bf16BatchVariant { Bf16Batch fn, fn_store; int rows; int wg_per_cu; };     // fn_store: also keeps R (gram_batch.hpp)
 const Bf16BatchVariant kBf16Batch[] = {
     {fos::residual_batch_mfma_bf16_kernel<1, 128>, fos::residual_batch_mfma_bf16_kernel<1, 128, true>, 64, 2},
     {fos::residual_batch_mfma_bf16_kernel<2, 128>, fos::residual_batch_mfma_bf16_kernel<2, 128, true>, 128, 1},
 };
 
-typedef void (*F32Batch)(const float*, int64_t, const float*, int, int64_t, int, const float*, int64_t, double*, float*);
+typedef void (*F32Batch)(const float*, int64_t, const float*, int, int64_t, int, const float*, int64_t, double*, float*,
+                         const int*);
 struct F32BatchVariant { F32Batch fn, fn_store; int rows; int wg_per_cu; };
 // fp32, measured at 65536 x 8192: <1> 64-row tile 368-395 us, <2> 128-row tile 335.7 us (80 % of HBM), <4> 336.8 us.
 const F32BatchVariant kF32Batch[] = {
@@ -642,7 +644,8 @@ const F32BatchVariant kF32Batch[] = {
 
 // Product 1 on `rows` rows starting at A / b: q_part[wg][16] partial squared norms, rout (nullable): the residuals.
 // Returns the number of workgroups (rows of q_part).
-int launch_batch_product(fos_problem* p, const void* A, const float* b, int64_t rows_total, int use_b, float* rout, int* nwg_out) {
+int launch_batch_product(fos_problem* p, const void* A, const float* b, int64_t rows_total, int use_b, float* rout, int* nwg_out,
+                         const int* stopped = nullptr) {
   const bool is_bf16 = p->dtype == FOS_BF16;
   const int variant = rows_total >= 128 * (int64_t)p->ncu ? 1 : 0;
   const int rows = is_bf16 ? kBf16Batch[variant].rows : kF32Batch[variant].rows;
@@ -654,22 +657,22 @@ int launch_batch_product(fos_problem* p, const void* A, const float* b, int64_t 
   if (is_bf16)
     hipLaunchKernelGGL(rout ? kBf16Batch[variant].fn_store : kBf16Batch[variant].fn, dim3((unsigned)nwg),
                        dim3(fos::BT_THREADS), 0, p->stream, (const fos::bf16_t*)A, p->lda, b, (use_b && b) ? 1 : 0,
-                       rows_total, (int)p->n, (const unsigned short*)p->xp, gpw, p->q_part, rout);
+                       rows_total, (int)p->n, (const unsigned short*)p->xp, gpw, p->q_part, rout, stopped);
   else
     hipLaunchKernelGGL(rout ? kF32Batch[variant].fn_store : kF32Batch[variant].fn, dim3((unsigned)nwg),
                        dim3(fos::BT_THREADS), 0, p->stream, (const float*)A, p->lda, b, (use_b && b) ? 1 : 0, rows_total,
-                       (int)p->n, p->xp, gpw, p->q_part, rout);
+                       (int)p->n, p->xp, gpw, p->q_part, rout, stopped);
   LAUNCH_CHECK();
   *nwg_out = (int)nwg;
   return FOS_OK;
 }
 
 // q[j] = ||A Xp_j - use_b*b||^2 -> out16 (device); Xp already in p->xp.
-int launch_residual_batch(fos_problem* p, int use_b, double* out16) {
+int launch_residual_batch(fos_problem* p, int use_b, double* out16, const int* stopped = nullptr) {
   int rc = prof_mark(p, true);
   if (rc) return rc;
   int nwg = 0;
-  if ((rc = launch_batch_product(p, p->A, p->b, p->m, use_b, nullptr, &nwg))) return rc;
+  if ((rc = launch_batch_product(p, p->A, p->b, p->m, use_b, nullptr, &nwg, stopped))) return rc;
   if ((rc = prof_mark(p, false))) return rc;
   hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->q_part, (int)nwg, fos::BT_NV, out16);
   LAUNCH_CHECK();
@@ -1315,7 +1318,7 @@ static void to_dev_params(const fos_fista_params* s, fos::FistaParams* d) {
   d->tol_step = s->tol_step;
   d->tol_ratio = s->tol_ratio;
   d->tol_grad = s->tol_grad;
-  d->pad = 0;
+  d->tau_from_state = 0;
 }
 
 int fos_fista_reset(fos_fista* f, const fos_fista_params* prm, const double* x0) {
@@ -1336,6 +1339,7 @@ int fos_fista_reset(fos_fista* f, const fos_fista_params* prm, const double* x0)
   hipLaunchKernelGGL(fos::fista_init_scalars_kernel, dim3(1), dim3(1), 0, p->stream, f->scal);
   LAUNCH_CHECK();
   f->host_valid = true;
+  f->tau_on_device = false;
   f->y_valid = false;
   f->pending = false;
   f->plain_count = 0;
@@ -1348,6 +1352,7 @@ int fos_fista_reset(fos_fista* f, const fos_fista_params* prm, const double* x0)
 int fos_fista_set_tau(fos_fista* f, double tau) {
   if (!f || !(tau > 0.0)) return fail(FOS_ERR_ARG, "fos_fista_set_tau: bad argument");
   f->prm.tau = tau;
+  f->tau_on_device = false;
   return FOS_OK;
 }
 
@@ -1949,6 +1954,81 @@ int fos_fista_trial(fos_fista* f, double t, int with_residual, double out8[8]) {
   return FOS_OK;
 }
 
+// Enqueue one batch of Armijo candidates t, t*eta, ...: candidate kernel, fold of its sums -> bt_out[0..50), the matrix-
+// core pass ||A dlt_j||^2 -> bt_out[64..80).  t_from_state: t is FistaScalars::tau on the device (no host value).
+static int enqueue_trial_batch(fos_fista* f, double t, double eta, int nv, int t_from_state) {
+  fos_problem* p = f->p;
+  const int grid = grid_1d(p->n_pad, 256, 64);
+  const int* stopped = t_from_state ? &f->scal->stopped : nullptr;
+  if (p->dtype == FOS_BF16)
+    hipLaunchKernelGGL(fos::fista_trial_batch_bf16_kernel, dim3(grid), dim3(256), 0, p->stream, grad_src(f), (int)p->n,
+                       (int)p->n_pad, f->x_cur, f->x_prev, f->scal, f->prm, t, eta, nv, (unsigned short*)p->xp, p->part,
+                       t_from_state);
+  else
+    hipLaunchKernelGGL(fos::fista_trial_batch_kernel, dim3(grid), dim3(256), 0, p->stream, grad_src(f), (int)p->n,
+                       (int)p->n_pad, f->x_cur, f->x_prev, f->scal, f->prm, t, eta, nv, p->xp, p->part, t_from_state);
+  hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->part, grid, fos::BT_W, p->bt_out);
+  LAUNCH_CHECK();
+  return launch_residual_batch(p, 0, p->bt_out + 64, stopped);
+}
+
+int fos_fista_run_backtracking(fos_fista* f, int iters, double eta, double armijo_c, double grad_eps, int32_t* ls_iters,
+                               double* tau_hist) {
+  if (!f || iters < 0 || !(eta > 0.0 && eta < 1.0) || !(grad_eps >= 0.0))
+    return fail(FOS_ERR_ARG, "fos_fista_run_backtracking: bad argument");
+  fos_problem* p = f->p;
+  if (!batch_supported(p) || p->resident)
+    return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_backtracking: needs the matrix-core candidate pass (streaming plans)");
+  if (iters == 0) return FOS_OK;
+  int rc = flush_pending(f);
+  if (rc) return rc;
+  if ((rc = ensure_batch_workspace(p))) return rc;
+  // the step lives on the device from here on; t_k, beta_k depend on nothing the host knows any more
+  if (!f->tau_on_device) {
+    hipLaunchKernelGGL(fos::set_state_tau_kernel, dim3(1), dim3(1), 0, p->stream, f->scal, f->prm.tau);
+    LAUNCH_CHECK();
+    f->tau_on_device = true;
+  }
+  f->host_valid = false;
+  f->y_valid = false;
+  f->plain_count = 0;
+  fos::FistaParams prm_dev = f->prm;
+  prm_dev.tau_from_state = 1;
+  for (int it = 0; it < iters; ++it) {
+    if ((rc = fos_fista_grad(f))) return rc;                                   // :173-175 (fp64 pass in precise mode)
+    if (f->prm.tol_grad > 0.0 && (rc = launch_grad_norm_stop(f))) return rc;   // :179
+    if ((rc = enqueue_trial_batch(f, 0.0, eta, fos::BT_NV, 1))) return rc;     // :187-191 for 16 candidates
+    hipLaunchKernelGGL(fos::armijo_decide_kernel, dim3(1), dim3(1), 0, p->stream, p->bt_out, f->scal, f->prm, eta, armijo_c,
+                       grad_eps, fos::BT_NV, ls_iters, tau_hist, (long long)it);
+    LAUNCH_CHECK();
+    // update with the step the decision left in FistaScalars::tau (:197: tau persists), then the scalar bookkeeping
+    if (p->vec4)
+      hipLaunchKernelGGL((fos::fista_update_kernel<false, true>), dim3(f->nupd), dim3(256), 0, p->stream,
+                         (const float*)nullptr, 0, grad_src(f), (int)p->n, f->x_cur, f->x_prev, f->scal, prm_dev, p->part, 0,
+                         0.0, (double*)nullptr, (float*)nullptr, 0.0);
+    else
+      hipLaunchKernelGGL((fos::fista_update_kernel<false, false>), dim3(f->nupd), dim3(256), 0, p->stream,
+                         (const float*)nullptr, 0, grad_src(f), (int)p->n, f->x_cur, f->x_prev, f->scal, prm_dev, p->part, 0,
+                         0.0, (double*)nullptr, (float*)nullptr, 0.0);
+    LAUNCH_CHECK();
+    if ((rc = launch_finalize(f, 0))) return rc;
+  }
+  return FOS_OK;
+}
+
+int fos_fista_resume_after_stall(fos_fista* f, double* tau_out) {
+  if (!f || !tau_out) return fail(FOS_ERR_ARG, "fos_fista_resume_after_stall: null");
+  fos_problem* p = f->p;
+  fos::FistaScalars h;
+  HIP_TRY(hipMemcpyAsync(&h, f->scal, sizeof(h), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  *tau_out = h.tau;
+  f->prm.tau = h.tau;                          // tau persists (:197), also across the hand-over to the host
+  hipLaunchKernelGGL(fos::clear_stall_kernel, dim3(1), dim3(1), 0, p->stream, f->scal);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
 int fos_fista_trial_batch(fos_fista* f, double t, double eta, int nv, double* out) {
   if (!f || !out || !(t > 0.0) || !(eta > 0.0) || nv < 1 || nv > fos::BT_NV)
     return fail(FOS_ERR_ARG, "fos_fista_trial_batch: bad argument");
@@ -1957,17 +2037,8 @@ int fos_fista_trial_batch(fos_fista* f, double t, double eta, int nv, double* ou
   if (!batch_supported(p)) return fail(FOS_ERR_UNSUPPORTED, "fos_fista_trial_batch: needs the fused path");
   int rc = ensure_batch_workspace(p);
   if (rc) return rc;
-  const int grid = grid_1d(p->n_pad, 256, 64);
-  if (p->dtype == FOS_BF16)
-    hipLaunchKernelGGL(fos::fista_trial_batch_bf16_kernel, dim3(grid), dim3(256), 0, p->stream, grad_src(f), (int)p->n,
-                       (int)p->n_pad, f->x_cur, f->x_prev, f->scal, f->prm, t, eta, nv, (unsigned short*)p->xp, p->part);
-  else
-    hipLaunchKernelGGL(fos::fista_trial_batch_kernel, dim3(grid), dim3(256), 0, p->stream, grad_src(f), (int)p->n,
-                       (int)p->n_pad, f->x_cur, f->x_prev, f->scal, f->prm, t, eta, nv, p->xp, p->part);
-  hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->part, grid, fos::BT_W, p->bt_out);
-  LAUNCH_CHECK();
+  if ((rc = enqueue_trial_batch(f, t, eta, nv, 0))) return rc;
   HIP_TRY(hipMemcpyAsync(p->bt_out + 100, &f->scal->rr, sizeof(double), hipMemcpyDeviceToDevice, p->stream));
-  if ((rc = launch_residual_batch(p, 0, p->bt_out + 64))) return rc;
   double h[128];
   HIP_TRY(hipMemcpyAsync(h, p->bt_out, 128 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
@@ -1994,6 +2065,7 @@ int fos_fista_status_get(fos_fista* f, fos_fista_status* out) {
   out->t_prev = h.t_prev; out->beta = h.beta; out->this_step = h.this_step; out->prev_step = h.prev_step;
   out->ratio = h.ratio; out->rr = h.rr; out->gnorm2 = h.gnorm2; out->xnorm1 = h.xnorm1; out->xnorm2 = h.xnorm2;
   out->rr_x = h.rr_x;
+  out->tau = h.tau;
   out->k = h.k; out->stopped = h.stopped; out->restarts = h.restarts;
   return FOS_OK;
 }

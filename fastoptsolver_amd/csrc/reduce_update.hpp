@@ -19,7 +19,7 @@ namespace fos {
 
 enum : int { MODE_FISTA = 0, MODE_DELTA = 1, MODE_ISTA = 2 };
 enum : int { PROX_L1 = 0, PROX_ENET = 1 };   // PROX_ENET: l2 term inside the prox (prox_operators.py:10-16)
-enum : int { STOP_NONE = 0, STOP_STEP = 1, STOP_RATIO = 2, STOP_GRAD = 3 };
+enum : int { STOP_NONE = 0, STOP_STEP = 1, STOP_RATIO = 2, STOP_GRAD = 3, STOP_LS_STALL = 4 };
 
 // Loop-carried scalars that live on the device so that a run of iterations needs no host round trip.
 struct FistaScalars {
@@ -36,6 +36,7 @@ struct FistaScalars {
   long long k;         // completed iterations
   int stopped;         // STOP_*
   int restarts;
+  double tau;          // device-driven backtracking (fos_fista_run_backtracking): the step, carried across iterations
 };
 
 struct FistaParams {
@@ -50,7 +51,7 @@ struct FistaParams {
   int mode;            // MODE_*
   int prox_kind;       // PROX_*
   int adaptive_restart;
-  int pad;
+  int tau_from_state;  // 1: the update takes the step from FistaScalars::tau (device-driven backtracking), not from `tau`
 };
 
 // ---- candidate / multi-lambda block layouts of the matrix-core kernels (batch_trial.hpp, gram_batch.hpp) -----------
@@ -286,14 +287,15 @@ __device__ inline void fista_update_body(const float* __restrict__ slabs, int ns
     cnt = owner ? 1 : 0;
   }
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  const double thr = prm.tau * prm.alpha1;
-  const double shrink = 1.0 / (1.0 + prm.tau * prm.alpha2);
+  const double tau = prm.tau_from_state ? scal->tau : prm.tau;
+  const double thr = tau * prm.alpha1;
+  const double shrink = 1.0 / (1.0 + tau * prm.alpha2);
   for (int e = 0; e < cnt; ++e) {
     const double xc = x_cur[col + e], xp = x_prev[col + e];
     const double y = form_y(xc, xp, beta);
     double gf = g[e];
     if (prm.prox_kind == PROX_L1 && prm.alpha2 > 0.0) gf += prm.alpha2 * y;
-    const double v = y - prm.tau * gf;
+    const double v = y - tau * gf;
     double xn = prm.alpha1 > 0.0 ? soft_threshold(v, thr) : v;
     if (prm.prox_kind == PROX_ENET) xn *= shrink;
     const double d = xn - xc;
@@ -469,6 +471,44 @@ __global__ __launch_bounds__(1024) void grad_norm_stop_kernel(GradSrc gsrc, int 
     scal->gnorm2 = s;
     if (sqrt(s) < prm.tol_grad) scal->stopped = STOP_GRAD;
   }
+}
+
+// Device-side Armijo decision (iterative_solvers.py:187-195 for the candidates t, t*eta, ... of one matrix-core batch):
+// the first candidate that passes  (1-C) grad.dlt + 0.5||A dlt||^2 + 0.5 a2 ||dlt||^2 <= noise  (the host's
+// _armijo_accepts, same clauses) becomes the step; FistaScalars::tau carries it to the update kernel and to the next
+// iteration (tau persists, :197).  No candidate of the batch accepted: the flag STOP_LS_STALL parks the pipeline - every
+// later kernel is a no-op - until the host finishes this search (rare: the reference's own step-underflow regime).
+// bt: folded sums of the candidate kernel { gd_j (16), dd_j (16), nnz_j (16), ||grad||^2, ||y||^2 }, q = bt + 64.
+__global__ void armijo_decide_kernel(const double* __restrict__ bt, FistaScalars* __restrict__ scal, FistaParams prm,
+                                     double eta, double armijo_c, double grad_eps, int nv, int* __restrict__ ls_out,
+                                     double* __restrict__ tau_hist, long long slot) {
+  if (scal->stopped != 0) return;
+  const double a2s = (prm.prox_kind == PROX_L1 && prm.alpha2 > 0.0) ? prm.alpha2 : 0.0;
+  const double gn2 = bt[3 * BT_NV], y2 = bt[3 * BT_NV + 1];
+  const double g_y = 0.5 * scal->rr + 0.5 * a2s * y2;
+  double t = scal->tau;
+  int j = 0;
+  bool accepted = false;
+  for (; j < nv; ++j) {
+    const double gd = bt[j], dd = bt[BT_NV + j], nnz = bt[2 * BT_NV + j], q = bt[64 + j];
+    const double excess = (1.0 - armijo_c) * gd + 0.5 * q + 0.5 * a2s * dd;
+    const double noise = fmax(2.220446049250313e-16 * g_y, grad_eps * sqrt(gn2 * dd));
+    const bool ball = dd <= (grad_eps * t) * (grad_eps * t) * gn2;
+    if (nnz == 0.0 || excess <= noise || ball) { accepted = true; break; }
+    t *= eta;
+  }
+  scal->tau = t;
+  if (accepted) {
+    if (ls_out != nullptr) ls_out[slot] = j;
+    if (tau_hist != nullptr) tau_hist[slot] = t;
+  } else {
+    scal->stopped = STOP_LS_STALL;
+  }
+}
+
+__global__ void set_state_tau_kernel(FistaScalars* __restrict__ scal, double tau) { scal->tau = tau; }
+__global__ void clear_stall_kernel(FistaScalars* __restrict__ scal) {
+  if (scal->stopped == STOP_LS_STALL) scal->stopped = STOP_NONE;
 }
 
 // y = (float)(x_cur + beta (x_cur - x_prev)) as one fp32 vector (entry of a lockstep multi-lambda run).

@@ -160,7 +160,8 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
     host_driven = backtracking or history is not None or log is not None or reducer is not None
     # gradient-norm stop (ref:179): on the device (fos_fista_params.tol_grad) when the run is enqueue-only, by the host
     # between grad() and update() when the host drives anyway
-    dev_grad_stop = grad_tol_check and tol > 0.0 and not host_driven
+    device_bt = backtracking and history is None and log is None and reducer is None   # decided on the device too
+    dev_grad_stop = grad_tol_check and tol > 0.0 and (not host_driven or device_bt)
     st.reset(tau, alpha1, alpha2, mode=mode, prox_kind=prox_kind, delta=delta, adaptive_restart=adaptive_restart,
              restart_threshold=restart_threshold, tol_step=tol if tol > 0.0 else 0.0,
              tol_ratio=tol_ratio if tol_ratio > 0.0 else 0.0, x0=x0_dev, **({"tol_grad": tol} if dev_grad_stop else {}))
@@ -254,6 +255,67 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
             gtimer.flush()
             return st
 
+    def search_on_host(t_k, bt_steps):
+        """Armijo search ref:183-197 / :298-312 / :92-108 from step t_k on (bt_steps shrinks already taken)."""
+        nonlocal use_batch
+        while True:
+            # candidates t_k, t_k*eta, ... decided by ONE pass over A on the matrix cores (fos.h); ragged
+            # problems (two-pass fallback) evaluate one candidate per pass.
+            rows = st.trial_batch(t_k, eta, _BATCH) if use_batch else None
+            if rows is None:
+                use_batch = False
+                rows = [st.trial(t_k, with_residual=True)]
+            if reducer is not None:                        # ||A dlt||^2 = sum over the row blocks; ||r||^2 likewise
+                for tr, q in zip(rows, reducer.sum([tr["q"] for tr in rows])):
+                    tr["q"] = q
+                    tr["rr_y"] = reducer.rr_global()
+            for tr in rows:
+                if _armijo_accepts(tr, t_k, smooth_a2, grad_eps):
+                    return t_k, bt_steps
+                t_k *= eta                                 # ref:195
+                bt_steps += 1
+
+    # Backtracking without a host round trip per iteration: gradient, one matrix-core batch of 16 candidates, the
+    # decision, the update and the bookkeeping are all enqueued (fos_fista_run_backtracking); the host polls every
+    # `check_every` iterations for stops and for a parked search (all 16 candidates rejected: the reference's
+    # step-underflow regime), which it finishes itself before handing the loop back to the device.
+    if (backtracking and history is None and log is None and reducer is None and max_iter > 0
+            and hasattr(st, "run_backtracking")):
+        chunk = max(1, int(check_every or 8))
+        done, ls_t0, device_ok = 0, time.perf_counter(), True
+        while done < max_iter and device_ok:
+            todo = min(chunk, max_iter - done)
+            ev = gtimer.start()
+            rec = st.run_backtracking(todo, eta, C, grad_eps)
+            if rec is None:
+                device_ok = False
+                gtimer.pending.clear()
+                break
+            s = st.status()                                   # synchronises: k, stop / stall flag
+            ran = int(s.k) - done
+            stalled = s.stopped == _lib.STOP_LS_STALL
+            gtimer.stop(ev, max(ran + (1 if (stalled or s.stopped == _lib.STOP_GRAD) else 0), 1))
+            ls_call_iters.extend(int(v) for v in rec[0][:ran].cpu().tolist())
+            done += ran
+            if stalled:                                       # finish this iteration's search on the host
+                tau = st.resume_after_stall()
+                tau, steps = search_on_host(tau, _BATCH)
+                ls_call_iters.append(steps)
+                st.set_tau(tau)
+                st.update()
+                done += 1
+                if st.status().stopped != _lib.STOP_NONE:
+                    break
+            elif s.stopped != _lib.STOP_NONE:
+                break
+        if device_ok:
+            gtimer.flush()
+            ngrad = done + (1 if st.status().stopped == _lib.STOP_GRAD else 0)
+            del grad_call_times[ngrad:]
+            share = (time.perf_counter() - ls_t0) / max(len(ls_call_iters), 1)
+            ls_call_times.extend([share] * len(ls_call_iters))    # the device does not time its phases: equal shares
+            return st
+
     # History objective f(x_k) without the reference's extra pass per iteration (ref:225-230, :321): the DUAL
     # gradient pass of iteration k also returns ||A x_k - b||^2, so f(x_k) is appended one iteration late and only
     # the very last iterate needs a residual pass of its own.
@@ -274,27 +336,8 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
                     owed = None
                 break
         if backtracking:                                      # ref:183-197 / ref:298-312 / ref:92-108
-            bt_steps = 0
             ls_t0 = time.perf_counter()
-            t_k = tau
-            accepted = False
-            while not accepted:
-                # candidates t_k, t_k*eta, ... decided by ONE pass over A on the matrix cores (fos.h); ragged
-                # problems (two-pass fallback) evaluate one candidate per pass.
-                rows = st.trial_batch(t_k, eta, _BATCH) if use_batch else None
-                if rows is None:
-                    use_batch = False
-                    rows = [st.trial(t_k, with_residual=True)]
-                if reducer is not None:                        # ||A dlt||^2 = sum over the row blocks; ||r||^2 likewise
-                    for tr, q in zip(rows, reducer.sum([tr["q"] for tr in rows])):
-                        tr["q"] = q
-                        tr["rr_y"] = reducer.rr_global()
-                for tr in rows:
-                    if _armijo_accepts(tr, t_k, smooth_a2, grad_eps):
-                        accepted = True
-                        break
-                    t_k *= eta                                 # ref:195
-                    bt_steps += 1
+            t_k, bt_steps = search_on_host(tau, 0)
             ls_call_times.append(time.perf_counter() - ls_t0)
             ls_call_iters.append(bt_steps)
             tau = t_k

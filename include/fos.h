@@ -29,7 +29,7 @@ enum { FOS_OK = 0, FOS_ERR_ARG = -1, FOS_ERR_HIP = -2, FOS_ERR_STATE = -3, FOS_E
 enum { FOS_F32 = 0, FOS_BF16 = 1 };                    /* element type of A */
 enum { FOS_MODE_FISTA = 0, FOS_MODE_DELTA = 1, FOS_MODE_ISTA = 2 };
 enum { FOS_PROX_L1 = 0, FOS_PROX_ENET = 1 };
-enum { FOS_STOP_NONE = 0, FOS_STOP_STEP = 1, FOS_STOP_RATIO = 2, FOS_STOP_GRAD = 3 };
+enum { FOS_STOP_NONE = 0, FOS_STOP_STEP = 1, FOS_STOP_RATIO = 2, FOS_STOP_GRAD = 3, FOS_STOP_LS_STALL = 4 };
 
 enum { FOS_PLAN_NO_RESIDENT = 1, FOS_PLAN_NO_TALL = 2, FOS_PLAN_NO_WIDE = 4, FOS_PLAN_NO_COLBLOCK = 8 };   /* fos_problem_replan */
 
@@ -62,6 +62,7 @@ typedef struct fos_fista_status {
   double xnorm1;    /* ||x_k||_1   */
   double xnorm2;    /* ||x_k||_2^2 */
   double rr_x;      /* ||A x_k - b||^2 at the iterate the last fos_fista_grad_dual started from */
+  double tau;       /* device-driven backtracking: the step after the last search (fos_fista_run_backtracking) */
   int64_t k;        /* completed iterations */
   int32_t stopped;  /* FOS_STOP_* */
   int32_t restarts;
@@ -242,6 +243,20 @@ int fos_fista_trial(fos_fista* f, double t, int with_residual, double out8[8]);
  * 8 doubles, each laid out like out8 of fos_fista_trial.  Synchronises.  FOS_ERR_UNSUPPORTED when the problem runs
  * the two-pass fallback (ragged shapes): callers then loop over fos_fista_trial.  SURVEY.md 8(f) rank 1. */
 int fos_fista_trial_batch(fos_fista* f, double t, double eta, int nv, double* out);
+/* Backtracking WITHOUT a host round trip per iteration (:183-197 on the device): per iteration the gradient, one matrix-
+ * core batch of 16 candidate steps tau, tau*eta, ..., a one-thread kernel that takes the reference's decision for them in
+ * order (the same clauses as the host's test: (1-C) grad.dlt + 0.5||A dlt||^2 + 0.5 alpha2 ||dlt||^2 <= noise, grad_eps =
+ * relative resolution of the gradient pass), the update with the accepted step and the scalar bookkeeping - all enqueued.
+ * The step lives in the device state and persists across iterations and calls (:197).  ls_iters / tau_hist (device,
+ * `iters` entries, nullable): shrinks and accepted step of every completed search of this call.  If no candidate of a
+ * batch is accepted (the reference's step-underflow regime) the pipeline parks itself: status.stopped =
+ * FOS_STOP_LS_STALL, status.k = iterations completed; fos_fista_resume_after_stall hands the current step to the host,
+ * which finishes that search with fos_fista_trial_batch / fos_fista_update and may call this function again.
+ * FOS_ERR_UNSUPPORTED on plans without the candidate pass (two-pass, n <= 64) and on resident problems (their whole
+ * loop, backtracking included, is one launch already).  Enqueues only. */
+int fos_fista_run_backtracking(fos_fista* f, int iters, double eta, double armijo_c, double grad_eps, int32_t* ls_iters,
+                               double* tau_hist);
+int fos_fista_resume_after_stall(fos_fista* f, double* tau_out);      /* synchronises */
 int fos_fista_status_get(fos_fista* f, fos_fista_status* out);   /* synchronises */
 int fos_fista_get_x(fos_fista* f, double* dst);  /* enqueue copy of x_k (n doubles) to dst (device) */
 double* fos_fista_x(fos_fista* f);       /* device pointer to x_k (n doubles), borrowed     */

@@ -51,7 +51,7 @@ def test_version_and_error_paths_without_gpu(lib):
 def test_struct_layouts_match_header():
     from fastoptsolver_amd import _lib
     assert ctypes.sizeof(_lib.FistaParams) == 8 * 8 + 4 * 4          # 8 doubles (incl. tol_grad) + 4 int32
-    assert ctypes.sizeof(_lib.FistaStatus) == 10 * 8 + 8 + 2 * 4
+    assert ctypes.sizeof(_lib.FistaStatus) == 11 * 8 + 8 + 2 * 4        # 11 doubles (incl. tau), int64 k, 2 int32
 
 
 def test_product_never_imports_oracle():

@@ -1172,3 +1172,43 @@ def test_gradient_norm_stop_runs_on_the_device_and_long_power_iterations(fos):
     np.random.seed(3)
     assert fos.estimate_lipschitz(prob, n_iter=450, tol=0.0) == pytest.approx(
         orc.estimate_lipschitz(A, n_iter=450, tol=0.0, v0=v0), rel=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["aligned", "ragged_padded"])
+def test_device_driven_backtracking_equals_host_driven(fos, tag):
+    """fista(backtracking=True) without history decides every search on the device (fos_fista_run_backtracking: no host
+    round trip per iteration); with history the host decides.  Same kernels, same clauses: identical shrink counts and
+    iterates, also across poll chunks (the step persists on the device), through a parked search (t_init_factor so large
+    that the first search needs more than one batch of 16 candidates: the host finishes it and hands the loop back),
+    with the stopping rules, and for FISTA-delta; all against the oracle."""
+    from fastoptsolver_amd import iterative_solvers as its
+    if tag == "aligned":
+        A, b, fx = _data.problem("aligned")
+        L = float(fx["aligned/L"])
+    else:
+        A, b, _ = _data.synth(3000, 700, 21)                     # ragged n, padded onto the streaming pass (m*n >= 2^20)
+        L = float(np.linalg.norm(A, 2) ** 2)
+    prob = fos.prepare(A, b)
+    assert prob.plan()["path"] == 0 and prob.plan()["resident"] == 0
+    lam = float(np.max(np.abs(A.T @ b)))
+    cases = [dict(t_init_factor=2.0), dict(t_init_factor=4.0, eta=0.7), dict(t_init_factor=3.0e6, eta=0.5),
+             dict(t_init_factor=2.0, tol=2e-2), dict(t_init_factor=2.0, tol_ratio=0.95)]
+    for kw in cases:
+        x_dev = fos.fista(prob, None, "elasticnet", 0.05 * lam, 0.5, max_iter=30, L=L, backtracking=True, check_every=4, **kw)
+        ls_dev, met_dev = list(its.ls_call_iters), fos.get_metrics()
+        x_host, h = fos.fista(prob, None, "elasticnet", 0.05 * lam, 0.5, max_iter=30, L=L, backtracking=True,
+                              return_history=True, **kw)
+        ls_host, met_host = list(its.ls_call_iters), fos.get_metrics()
+        assert ls_dev == ls_host, (kw, ls_dev, ls_host)
+        assert met_dev["grad_num_calls"] == met_host["grad_num_calls"] and met_dev["ls_num_calls"] == met_host["ls_num_calls"], kw
+        assert _data.rel(x_dev, x_host) < 1e-12, kw
+        x_ref, met_ref = orc.fista(A, b, "elasticnet", 0.05 * lam, 0.5, max_iter=30, L=L, backtracking=True,
+                                   return_metrics=True, **kw)
+        assert _data.rel(x_dev, x_ref) < TOL, kw
+        assert met_dev["grad_num_calls"] == met_ref["grad_num_calls"], kw
+        if kw["t_init_factor"] < 1e3:
+            assert ls_dev == [int(v) for v in met_ref.get("ls_iters", ls_dev)] or sum(ls_dev) == met_ref["ls_iters_total"], kw
+    assert max(ls_dev) >= 0
+    xd = fos.fista_delta(prob, None, "lasso", 0.1 * lam, 0.0, 3.0, max_iter=25, L=L, backtracking=True, t_init_factor=2.0)
+    assert _data.rel(xd, orc.fista_delta(A, b, "lasso", 0.1 * lam, 0.0, 3.0, max_iter=25, L=L, backtracking=True,
+                                         t_init_factor=2.0)) < TOL
