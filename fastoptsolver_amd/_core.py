@@ -360,6 +360,25 @@ class Fista:
         _lib.check(rc, "fos_fista_run_backtracking")
         return ls, taus
 
+    def run_recorded(self, iters, backtracking, eta, armijo_c, grad_eps):
+        """Device-driven iterations with the history recorded on the device (fos_fista_run_recorded).  Returns dict of
+        device tensors x [iters, n], hist [iters, 4], rr_seen [iters], ls [iters], taus [iters] - or None when
+        unsupported for this plan."""
+        dev, iters = self.prob.device, int(iters)
+        rec = dict(x=torch.empty(max(iters, 1), self.prob.n_dev, dtype=torch.float64, device=dev),
+                   hist=torch.zeros(max(iters, 1), 4, dtype=torch.float64, device=dev),
+                   rr_seen=torch.full((max(iters, 1),), float("nan"), dtype=torch.float64, device=dev),
+                   ls=torch.zeros(max(iters, 1), dtype=torch.int32, device=dev),
+                   taus=torch.zeros(max(iters, 1), dtype=torch.float64, device=dev))
+        with self.prob.ctx():
+            rc = self.lib.fos_fista_run_recorded(self.h, iters, int(bool(backtracking)), float(eta), float(armijo_c),
+                                                 float(grad_eps), ptr(rec["x"]), ptr(rec["hist"]), ptr(rec["rr_seen"]),
+                                                 ptr(rec["ls"]), ptr(rec["taus"]))
+        if rc == -4:
+            return None
+        _lib.check(rc, "fos_fista_run_recorded")
+        return rec
+
     def resume_after_stall(self):
         """The device parked a search whose 16 candidates were all rejected: take the current step back to the host."""
         tau = C.c_double()

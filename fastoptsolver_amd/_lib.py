@@ -92,6 +92,7 @@ SIGNATURES = {
     "fos_fista_trial": (_i32, [_vp, _f64, _i32, C.POINTER(_f64)]),   # out8
     "fos_fista_trial_batch": (_i32, [_vp, _f64, _f64, _i32, C.POINTER(_f64)]),
     "fos_fista_run_backtracking": (_i32, [_vp, _i32, _f64, _f64, _f64, _vp, _vp]),
+    "fos_fista_run_recorded": (_i32, [_vp, _i32, _i32, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp]),
     "fos_fista_resume_after_stall": (_i32, [_vp, C.POINTER(_f64)]),
     "fos_fista_status_get": (_i32, [_vp, C.POINTER(FistaStatus)]),
     "fos_fista_get_x": (_i32, [_vp, _vp]),

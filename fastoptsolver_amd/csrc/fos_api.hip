@@ -1376,10 +1376,10 @@ static YSource fista_source(fos_fista* f) {
   return YSource{nullptr, f->x_cur, f->x_prev, &f->scal->beta, &f->scal->stopped, 0.0};
 }
 
-static int launch_finalize(fos_fista* f, int n_rr) {
+static int launch_finalize(fos_fista* f, int n_rr, double* hist_row = nullptr) {
   fos_problem* p = f->p;
   hipLaunchKernelGGL(fos::fista_finalize_kernel, dim3(1), dim3(64), 0, p->stream, p->part, f->nupd, p->rr_part, n_rr,
-                     f->scal, f->prm);
+                     f->scal, f->prm, hist_row);
   LAUNCH_CHECK();
   return FOS_OK;
 }
@@ -1972,6 +1972,61 @@ static int enqueue_trial_batch(fos_fista* f, double t, double eta, int nv, int t
   return launch_residual_batch(p, 0, p->bt_out + 64, stopped);
 }
 
+// Device-driven iterations with data-dependent control - Armijo search, adaptive restart, the stopping rules - and,
+// optionally, the history recorded on the device.  One body behind fos_fista_run_backtracking and fos_fista_run_recorded.
+static int run_device_driven(fos_fista* f, int iters, bool backtracking, double eta, double armijo_c, double grad_eps,
+                             int32_t* ls_iters, double* tau_hist, double* x_hist, double* hist, double* rr_seen) {
+  fos_problem* p = f->p;
+  int rc = flush_pending(f);
+  if (rc) return rc;
+  if (backtracking) {
+    if ((rc = ensure_batch_workspace(p))) return rc;
+    // the step lives on the device from here on (tau persists, :197)
+    if (!f->tau_on_device) {
+      hipLaunchKernelGGL(fos::set_state_tau_kernel, dim3(1), dim3(1), 0, p->stream, f->scal, f->prm.tau);
+      LAUNCH_CHECK();
+      f->tau_on_device = true;
+    }
+  }
+  f->host_valid = false;                       // t_k, beta_k depend on nothing the host knows any more
+  f->y_valid = false;
+  f->plain_count = 0;
+  fos::FistaParams prm_dev = f->prm;
+  prm_dev.tau_from_state = backtracking ? 1 : 0;
+  const bool record = hist != nullptr;
+  for (int it = 0; it < iters; ++it) {
+    // gradient (:173-175; the fp64 pass in precise mode); recording: the same pass (or a residual pass of its own where
+    // there is no DUAL kernel) also yields ||A x_k - b||^2 of the iterate this iteration starts from
+    if (record) {
+      if ((rc = fos_fista_grad_dual(f))) return rc;
+      hipLaunchKernelGGL(fos::record_rr_x_kernel, dim3(1), dim3(1), 0, p->stream, f->scal, rr_seen + it);
+      LAUNCH_CHECK();
+    } else if ((rc = fos_fista_grad(f))) {
+      return rc;
+    }
+    if (f->prm.tol_grad > 0.0 && (rc = launch_grad_norm_stop(f))) return rc;   // :179
+    if (backtracking) {
+      if ((rc = enqueue_trial_batch(f, 0.0, eta, fos::BT_NV, 1))) return rc;   // :187-191 for 16 candidates
+      hipLaunchKernelGGL(fos::armijo_decide_kernel, dim3(1), dim3(1), 0, p->stream, p->bt_out, f->scal, f->prm, eta,
+                         armijo_c, grad_eps, fos::BT_NV, ls_iters, tau_hist, (long long)it);
+      LAUNCH_CHECK();
+    }
+    // update (with the step the decision left in FistaScalars::tau), then the scalar bookkeeping / history row
+    double* xrow = x_hist ? x_hist + (size_t)it * p->n : nullptr;
+    if (p->vec4)
+      hipLaunchKernelGGL((fos::fista_update_kernel<false, true>), dim3(f->nupd), dim3(256), 0, p->stream,
+                         (const float*)nullptr, 0, grad_src(f), (int)p->n, f->x_cur, f->x_prev, f->scal, prm_dev, p->part, 0,
+                         0.0, xrow, (float*)nullptr, 0.0);
+    else
+      hipLaunchKernelGGL((fos::fista_update_kernel<false, false>), dim3(f->nupd), dim3(256), 0, p->stream,
+                         (const float*)nullptr, 0, grad_src(f), (int)p->n, f->x_cur, f->x_prev, f->scal, prm_dev, p->part, 0,
+                         0.0, xrow, (float*)nullptr, 0.0);
+    LAUNCH_CHECK();
+    if ((rc = launch_finalize(f, 0, record ? hist + (size_t)it * 4 : nullptr))) return rc;
+  }
+  return FOS_OK;
+}
+
 int fos_fista_run_backtracking(fos_fista* f, int iters, double eta, double armijo_c, double grad_eps, int32_t* ls_iters,
                                double* tau_hist) {
   if (!f || iters < 0 || !(eta > 0.0 && eta < 1.0) || !(grad_eps >= 0.0))
@@ -1980,40 +2035,20 @@ int fos_fista_run_backtracking(fos_fista* f, int iters, double eta, double armij
   if (!batch_supported(p) || p->resident)
     return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_backtracking: needs the matrix-core candidate pass (streaming plans)");
   if (iters == 0) return FOS_OK;
-  int rc = flush_pending(f);
-  if (rc) return rc;
-  if ((rc = ensure_batch_workspace(p))) return rc;
-  // the step lives on the device from here on; t_k, beta_k depend on nothing the host knows any more
-  if (!f->tau_on_device) {
-    hipLaunchKernelGGL(fos::set_state_tau_kernel, dim3(1), dim3(1), 0, p->stream, f->scal, f->prm.tau);
-    LAUNCH_CHECK();
-    f->tau_on_device = true;
-  }
-  f->host_valid = false;
-  f->y_valid = false;
-  f->plain_count = 0;
-  fos::FistaParams prm_dev = f->prm;
-  prm_dev.tau_from_state = 1;
-  for (int it = 0; it < iters; ++it) {
-    if ((rc = fos_fista_grad(f))) return rc;                                   // :173-175 (fp64 pass in precise mode)
-    if (f->prm.tol_grad > 0.0 && (rc = launch_grad_norm_stop(f))) return rc;   // :179
-    if ((rc = enqueue_trial_batch(f, 0.0, eta, fos::BT_NV, 1))) return rc;     // :187-191 for 16 candidates
-    hipLaunchKernelGGL(fos::armijo_decide_kernel, dim3(1), dim3(1), 0, p->stream, p->bt_out, f->scal, f->prm, eta, armijo_c,
-                       grad_eps, fos::BT_NV, ls_iters, tau_hist, (long long)it);
-    LAUNCH_CHECK();
-    // update with the step the decision left in FistaScalars::tau (:197: tau persists), then the scalar bookkeeping
-    if (p->vec4)
-      hipLaunchKernelGGL((fos::fista_update_kernel<false, true>), dim3(f->nupd), dim3(256), 0, p->stream,
-                         (const float*)nullptr, 0, grad_src(f), (int)p->n, f->x_cur, f->x_prev, f->scal, prm_dev, p->part, 0,
-                         0.0, (double*)nullptr, (float*)nullptr, 0.0);
-    else
-      hipLaunchKernelGGL((fos::fista_update_kernel<false, false>), dim3(f->nupd), dim3(256), 0, p->stream,
-                         (const float*)nullptr, 0, grad_src(f), (int)p->n, f->x_cur, f->x_prev, f->scal, prm_dev, p->part, 0,
-                         0.0, (double*)nullptr, (float*)nullptr, 0.0);
-    LAUNCH_CHECK();
-    if ((rc = launch_finalize(f, 0))) return rc;
-  }
-  return FOS_OK;
+  return run_device_driven(f, iters, true, eta, armijo_c, grad_eps, ls_iters, tau_hist, nullptr, nullptr, nullptr);
+}
+
+int fos_fista_run_recorded(fos_fista* f, int iters, int backtracking, double eta, double armijo_c, double grad_eps,
+                           double* x_hist, double* hist, double* rr_seen, int32_t* ls_iters, double* tau_hist) {
+  if (!f || iters < 0 || (iters > 0 && (!x_hist || !hist || !rr_seen)) ||
+      (backtracking && (!(eta > 0.0 && eta < 1.0) || !(grad_eps >= 0.0))))
+    return fail(FOS_ERR_ARG, "fos_fista_run_recorded: bad argument");
+  fos_problem* p = f->p;
+  if (p->resident || (backtracking && !batch_supported(p)))
+    return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_recorded: resident problems record inside their one launch; "
+                                     "backtracking needs the matrix-core candidate pass");
+  if (iters == 0) return FOS_OK;
+  return run_device_driven(f, iters, backtracking != 0, eta, armijo_c, grad_eps, ls_iters, tau_hist, x_hist, hist, rr_seen);
 }
 
 int fos_fista_resume_after_stall(fos_fista* f, double* tau_out) {

@@ -369,7 +369,8 @@ __global__ __launch_bounds__(256) void fista_update_multi_kernel(const float* __
 // One wave: fold the partials and advance the scalar state.  iterative_solvers.py:204-221, :235-242, :325-342.
 __global__ __launch_bounds__(64) void fista_finalize_kernel(const double* __restrict__ part, int nparts,
                                                            const double* __restrict__ rr_part, int n_rr,
-                                                           FistaScalars* __restrict__ scal, FistaParams prm) {
+                                                           FistaScalars* __restrict__ scal, FistaParams prm,
+                                                           double* __restrict__ hist_row = nullptr) {
   if (scal->stopped != 0) return;
   // issue every load before the first use: the partials were written by other CUs (L2 / MALL latency each)
   double s[4] = {0.0, 0.0, 0.0, 0.0};
@@ -431,6 +432,9 @@ __global__ __launch_bounds__(64) void fista_finalize_kernel(const double* __rest
   scal->xnorm2 = s[3];
   if (n_rr > 0) scal->rr = rr;
   scal->k += 1;
+  if (hist_row != nullptr) {        // device-recorded history (fos_fista_run_recorded): { -, ||x||_1, ||x||_2^2, ||dx||^2 }
+    hist_row[1] = s[2]; hist_row[2] = s[3]; hist_row[3] = s[0];
+  }
   int stop = STOP_NONE;
   if (prm.tol_step > 0.0 && step < prm.tol_step) stop = STOP_STEP;
   if (stop == STOP_NONE && prm.tol_ratio > 0.0 && ratio < prm.tol_ratio) stop = STOP_RATIO;
@@ -507,6 +511,11 @@ __global__ void armijo_decide_kernel(const double* __restrict__ bt, FistaScalars
 }
 
 __global__ void set_state_tau_kernel(FistaScalars* __restrict__ scal, double tau) { scal->tau = tau; }
+// ||A x_k - b||^2 seen by this iteration's gradient pass (the iterate BEFORE the update) -> its slot of the record
+__global__ void record_rr_x_kernel(const FistaScalars* __restrict__ scal, double* __restrict__ slot) {
+  if (scal->stopped != 0) return;
+  *slot = scal->rr_x;
+}
 __global__ void clear_stall_kernel(FistaScalars* __restrict__ scal) {
   if (scal->stopped == STOP_LS_STALL) scal->stopped = STOP_NONE;
 }

@@ -160,8 +160,8 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
     host_driven = backtracking or history is not None or log is not None or reducer is not None
     # gradient-norm stop (ref:179): on the device (fos_fista_params.tol_grad) when the run is enqueue-only, by the host
     # between grad() and update() when the host drives anyway
-    device_bt = backtracking and history is None and log is None and reducer is None   # decided on the device too
-    dev_grad_stop = grad_tol_check and tol > 0.0 and (not host_driven or device_bt)
+    device_loop = log is None and reducer is None              # every such configuration has an enqueue-only form
+    dev_grad_stop = grad_tol_check and tol > 0.0 and (not host_driven or device_loop)
     st.reset(tau, alpha1, alpha2, mode=mode, prox_kind=prox_kind, delta=delta, adaptive_restart=adaptive_restart,
              restart_threshold=restart_threshold, tol_step=tol if tol > 0.0 else 0.0,
              tol_ratio=tol_ratio if tol_ratio > 0.0 else 0.0, x0=x0_dev, **({"tol_grad": tol} if dev_grad_stop else {}))
@@ -255,6 +255,13 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
             gtimer.flush()
             return st
 
+    def refresh_gradient_after_stall():
+        """Sharded problem: the iterations enqueued behind a parked search are no-ops on the device, but their in-place
+        all-reduces still ran - on the parked gradient, which they scaled by the number of ranks each time.  One fresh
+        gradient pass restores it before the host finishes the search (a parked search is a rare event)."""
+        if getattr(prob, "comm", None) is not None:
+            st.grad()
+
     def search_on_host(t_k, bt_steps):
         """Armijo search ref:183-197 / :298-312 / :92-108 from step t_k on (bt_steps shrinks already taken)."""
         nonlocal use_batch
@@ -299,6 +306,7 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
             done += ran
             if stalled:                                       # finish this iteration's search on the host
                 tau = st.resume_after_stall()
+                refresh_gradient_after_stall()
                 tau, steps = search_on_host(tau, _BATCH)
                 ls_call_iters.append(steps)
                 st.set_tau(tau)
@@ -314,6 +322,65 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
             del grad_call_times[ngrad:]
             share = (time.perf_counter() - ls_t0) / max(len(ls_call_iters), 1)
             ls_call_times.extend([share] * len(ls_call_iters))    # the device does not time its phases: equal shares
+            return st
+
+    # History of the configurations with data-dependent control (backtracking, adaptive restart, stopping rules) recorded
+    # on the device as well (fos_fista_run_recorded): iterates and their norms per iteration, ||A x - b||^2 of every
+    # iterate out of the NEXT iteration's gradient pass; the host polls every `check_every` iterations, finishes a parked
+    # search itself, and closes the last objective with one residual pass.
+    if history is not None and log is None and reducer is None and max_iter > 0 and hasattr(st, "run_recorded"):
+        chunk = max(1, min(int(check_every or 16), _HISTORY_CHUNK_BYTES // (8 * prob.n_dev)))
+        done, started_total, supported, ls_t0 = 0, 0, True, time.perf_counter()
+        rr_seen, norms = [], []                # rr_seen[t]: residual of the iterate iteration t started from
+        while done < max_iter:
+            todo = min(chunk, max_iter - done)
+            ev = gtimer.start()
+            rec = st.run_recorded(todo, backtracking, eta, C, grad_eps)
+            if rec is None:
+                supported = False
+                gtimer.pending.clear()
+                break
+            s = st.status()                                   # synchronises
+            ran = int(s.k) - done
+            stalled = s.stopped == _lib.STOP_LS_STALL
+            started = ran + (1 if (stalled or s.stopped == _lib.STOP_GRAD) else 0)
+            gtimer.stop(ev, max(started, 1))
+            started_total += started
+            rr_seen.extend(rec["rr_seen"][:started].cpu().tolist())
+            hs = rec["hist"][:ran].cpu().numpy()
+            xh = prob.vec_out(rec["x"][:ran])
+            if like.tensor:
+                history["x"].extend(_core.from_device_vec(xh[i], like) for i in range(ran))
+            else:
+                history["x"].extend(list(xh.cpu().numpy()))
+            norms.extend((float(r[1]), float(r[2])) for r in hs)
+            if backtracking:
+                ls_call_iters.extend(int(v) for v in rec["ls"][:ran].cpu().tolist())
+            done += ran
+            if stalled:                                       # finish this iteration's search on the host
+                tau = st.resume_after_stall()
+                refresh_gradient_after_stall()
+                tau, steps = search_on_host(tau, _BATCH)
+                ls_call_iters.append(steps)
+                st.set_tau(tau)
+                st.update()
+                s = st.status()
+                history["x"].append(_core.from_device_vec(st.x_tensor(), like))
+                norms.append((s.xnorm1, s.xnorm2))
+                done += 1
+            if s.stopped != _lib.STOP_NONE:
+                break
+        if supported:
+            gtimer.flush()
+            del grad_call_times[started_total:]
+            if backtracking:
+                share = (time.perf_counter() - ls_t0) / max(len(ls_call_iters), 1)
+                ls_call_times.extend([share] * len(ls_call_iters))
+            # f(x after iteration t) needs ||A x - b||^2 of that iterate: seen by iteration t + 1, or by a closing pass
+            rr_of = rr_seen[1:done + 1]
+            if len(rr_of) < done:
+                rr_of.append(prob.residual_objective(st.x_tensor())[0])
+            history["obj"].extend(history_obj(rr, x2, x1) for rr, (x1, x2) in zip(rr_of, norms))
             return st
 
     # History objective f(x_k) without the reference's extra pass per iteration (ref:225-230, :321): the DUAL

@@ -106,7 +106,10 @@ int fos_problem_set_gbuf(fos_problem* p, float* gbuf);
  * iteration - is summed over the ranks on the handle's stream before anything consumes it: ONE all-reduce of n + 1
  * floats per FISTA iteration (n + 1 doubles per L-BFGS fg), alpha2*y added after the reduction.  x_k, x_{k-1} and the
  * momentum scalars are replicated; every rank computes the identical update from identical numbers.  fos_fista_run
- * stays enqueue-only.  All ranks must issue the same calls in the same order.
+ * stays enqueue-only.  All ranks must issue the same calls in the same order.  (After a device-side stop or a parked
+ * search the remaining enqueued iterations are no-ops, but their in-place all-reduces still run on the stale gradient
+ * buffer, scaling it by the number of ranks each time: the iterate state is untouched, the gradient buffer is not - take a
+ * fresh fos_fista_grad before using it again, as the Python layer does when it resumes a parked search.)
  * Transport: RCCL over xGMI, resolved with dlopen at first use (fos_comm_transport() says which library), or the
  * one-shot full-mesh kernel below.
  *   fos_comm_unique_id   rank 0 creates the 128-byte id; the caller broadcasts it out of band (e.g. torch.distributed)
@@ -256,6 +259,18 @@ int fos_fista_trial_batch(fos_fista* f, double t, double eta, int nv, double* ou
  * loop, backtracking included, is one launch already).  Enqueues only. */
 int fos_fista_run_backtracking(fos_fista* f, int iters, double eta, double armijo_c, double grad_eps, int32_t* ls_iters,
                                double* tau_hist);
+/* The same device-driven loop with the history (:224-232, :319-322) recorded on the device, for every configuration with
+ * data-dependent control (backtracking = 1: Armijo search as above; adaptive restart and the stopping rules of
+ * fos_fista_params in either case) - the plain configurations have fos_fista_run_history.  Per iteration i of this call:
+ *   x_hist   row i  = the iterate after the iteration (iters x n doubles)
+ *   hist     row i  = { unused, ||x||_1, ||x||_2^2, ||x - x_before||^2 } of that iterate (iters x 4 doubles)
+ *   rr_seen  [i]    = ||A x - b||^2 of the iterate the iteration STARTED from (it comes out of the gradient pass - DUAL
+ *                     kernel - or a residual pass of its own in precise mode), i.e. the objective ingredient of the
+ *                     previous row; the caller closes the last row with one fos_residual_objective.
+ * Rows of iterations that did not complete (stop, parked search) are not written; status.k says how many did.
+ * Enqueues only. */
+int fos_fista_run_recorded(fos_fista* f, int iters, int backtracking, double eta, double armijo_c, double grad_eps,
+                           double* x_hist, double* hist, double* rr_seen, int32_t* ls_iters, double* tau_hist);
 int fos_fista_resume_after_stall(fos_fista* f, double* tau_out);      /* synchronises */
 int fos_fista_status_get(fos_fista* f, fos_fista_status* out);   /* synchronises */
 int fos_fista_get_x(fos_fista* f, double* dst);  /* enqueue copy of x_k (n doubles) to dst (device) */
