@@ -16,7 +16,7 @@ for m, n in ((65536, 8192), (16384, 2048), (4096, 1024), (20000, 256)):
     lam = float((A.T @ b).abs().max())
     L = float(m + n + 2.0 * (m * n) ** 0.5)
     res = {}
-    for name, kw in (("device-driven", {}), ("host-driven", dict(return_history=True))):
+    for name, kw in (("device-driven", {}), ("device-driven with history", dict(return_history=True))):
         fos.fista(prob, None, "lasso", 0.1 * lam, 0.0, max_iter=5, L=L, backtracking=True, t_init_factor=2.0, **kw)
         iters = 60
         torch.cuda.synchronize()
