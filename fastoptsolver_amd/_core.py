@@ -360,7 +360,7 @@ class Fista:
         _lib.check(rc, "fos_fista_run_backtracking")
         return ls, taus
 
-    def run_recorded(self, iters, backtracking, eta, armijo_c, grad_eps):
+    def run_recorded(self, iters, backtracking, eta, armijo_c, grad_eps, want_rr=True):
         """Device-driven iterations with the history recorded on the device (fos_fista_run_recorded).  Returns dict of
         device tensors x [iters, n], hist [iters, 4], rr_seen [iters], ls [iters], taus [iters] - or None when
         unsupported for this plan."""
@@ -372,7 +372,8 @@ class Fista:
                    taus=torch.zeros(max(iters, 1), dtype=torch.float64, device=dev))
         with self.prob.ctx():
             rc = self.lib.fos_fista_run_recorded(self.h, iters, int(bool(backtracking)), float(eta), float(armijo_c),
-                                                 float(grad_eps), ptr(rec["x"]), ptr(rec["hist"]), ptr(rec["rr_seen"]),
+                                                 float(grad_eps), ptr(rec["x"]), ptr(rec["hist"]),
+                                                 ptr(rec["rr_seen"] if want_rr else None),
                                                  ptr(rec["ls"]), ptr(rec["taus"]))
         if rc == -4:
             return None

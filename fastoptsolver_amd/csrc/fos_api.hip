@@ -1997,7 +1997,7 @@ static int run_device_driven(fos_fista* f, int iters, bool backtracking, double 
   for (int it = 0; it < iters; ++it) {
     // gradient (:173-175; the fp64 pass in precise mode); recording: the same pass (or a residual pass of its own where
     // there is no DUAL kernel) also yields ||A x_k - b||^2 of the iterate this iteration starts from
-    if (record) {
+    if (record && rr_seen != nullptr) {
       if ((rc = fos_fista_grad_dual(f))) return rc;
       hipLaunchKernelGGL(fos::record_rr_x_kernel, dim3(1), dim3(1), 0, p->stream, f->scal, rr_seen + it);
       LAUNCH_CHECK();
@@ -2040,7 +2040,7 @@ int fos_fista_run_backtracking(fos_fista* f, int iters, double eta, double armij
 
 int fos_fista_run_recorded(fos_fista* f, int iters, int backtracking, double eta, double armijo_c, double grad_eps,
                            double* x_hist, double* hist, double* rr_seen, int32_t* ls_iters, double* tau_hist) {
-  if (!f || iters < 0 || (iters > 0 && (!x_hist || !hist || !rr_seen)) ||
+  if (!f || iters < 0 || (iters > 0 && (!x_hist || !hist)) ||
       (backtracking && (!(eta > 0.0 && eta < 1.0) || !(grad_eps >= 0.0))))
     return fail(FOS_ERR_ARG, "fos_fista_run_recorded: bad argument");
   fos_problem* p = f->p;

@@ -160,7 +160,7 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
     host_driven = backtracking or history is not None or log is not None or reducer is not None
     # gradient-norm stop (ref:179): on the device (fos_fista_params.tol_grad) when the run is enqueue-only, by the host
     # between grad() and update() when the host drives anyway
-    device_loop = log is None and reducer is None              # every such configuration has an enqueue-only form
+    device_loop = reducer is None                               # every such configuration has an enqueue-only form
     dev_grad_stop = grad_tol_check and tol > 0.0 and (not host_driven or device_loop)
     st.reset(tau, alpha1, alpha2, mode=mode, prox_kind=prox_kind, delta=delta, adaptive_restart=adaptive_restart,
              restart_threshold=restart_threshold, tol_step=tol if tol > 0.0 else 0.0,
@@ -328,14 +328,14 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
     # on the device as well (fos_fista_run_recorded): iterates and their norms per iteration, ||A x - b||^2 of every
     # iterate out of the NEXT iteration's gradient pass; the host polls every `check_every` iterations, finishes a parked
     # search itself, and closes the last objective with one residual pass.
-    if history is not None and log is None and reducer is None and max_iter > 0 and hasattr(st, "run_recorded"):
+    if (history is not None or log is not None) and reducer is None and max_iter > 0 and hasattr(st, "run_recorded"):
         chunk = max(1, min(int(check_every or 16), _HISTORY_CHUNK_BYTES // (8 * prob.n_dev)))
         done, started_total, supported, ls_t0 = 0, 0, True, time.perf_counter()
         rr_seen, norms = [], []                # rr_seen[t]: residual of the iterate iteration t started from
         while done < max_iter:
             todo = min(chunk, max_iter - done)
             ev = gtimer.start()
-            rec = st.run_recorded(todo, backtracking, eta, C, grad_eps)
+            rec = st.run_recorded(todo, backtracking, eta, C, grad_eps, want_rr=history is not None)
             if rec is None:
                 supported = False
                 gtimer.pending.clear()
@@ -346,13 +346,18 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
             started = ran + (1 if (stalled or s.stopped == _lib.STOP_GRAD) else 0)
             gtimer.stop(ev, max(started, 1))
             started_total += started
-            rr_seen.extend(rec["rr_seen"][:started].cpu().tolist())
+            if history is not None:
+                rr_seen.extend(rec["rr_seen"][:started].cpu().tolist())
             hs = rec["hist"][:ran].cpu().numpy()
             xh = prob.vec_out(rec["x"][:ran])
-            if like.tensor:
-                history["x"].extend(_core.from_device_vec(xh[i], like) for i in range(ran))
-            else:
-                history["x"].extend(list(xh.cpu().numpy()))
+            as_tensor = like.tensor if hasattr(like, "tensor") else _core.is_tensor(like)    # ista passes x0 itself
+            rows = [_core.from_device_vec(xh[i], like) for i in range(ran)] if as_tensor else list(xh.cpu().numpy())
+            if history is not None:
+                history["x"].extend(rows)
+            if log is not None:                                # ista's log (ref:117-120): x, the step used, ||dx||
+                log["x"].extend(rows)
+                log["t"].extend(rec["taus"][:ran].cpu().tolist() if backtracking else [tau] * ran)
+                log["delta"].extend(float(math.sqrt(r[3])) for r in hs)
             norms.extend((float(r[1]), float(r[2])) for r in hs)
             if backtracking:
                 ls_call_iters.extend(int(v) for v in rec["ls"][:ran].cpu().tolist())
@@ -365,7 +370,13 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
                 st.set_tau(tau)
                 st.update()
                 s = st.status()
-                history["x"].append(_core.from_device_vec(st.x_tensor(), like))
+                row = _core.from_device_vec(st.x_tensor(), like)
+                if history is not None:
+                    history["x"].append(row)
+                if log is not None:
+                    log["x"].append(row)
+                    log["t"].append(tau)
+                    log["delta"].append(s.this_step)
                 norms.append((s.xnorm1, s.xnorm2))
                 done += 1
             if s.stopped != _lib.STOP_NONE:
@@ -377,10 +388,11 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
                 share = (time.perf_counter() - ls_t0) / max(len(ls_call_iters), 1)
                 ls_call_times.extend([share] * len(ls_call_iters))
             # f(x after iteration t) needs ||A x - b||^2 of that iterate: seen by iteration t + 1, or by a closing pass
-            rr_of = rr_seen[1:done + 1]
-            if len(rr_of) < done:
-                rr_of.append(prob.residual_objective(st.x_tensor())[0])
-            history["obj"].extend(history_obj(rr, x2, x1) for rr, (x1, x2) in zip(rr_of, norms))
+            if history is not None:
+                rr_of = rr_seen[1:done + 1]
+                if len(rr_of) < done:
+                    rr_of.append(prob.residual_objective(st.x_tensor())[0])
+                history["obj"].extend(history_obj(rr, x2, x1) for rr, (x1, x2) in zip(rr_of, norms))
             return st
 
     # History objective f(x_k) without the reference's extra pass per iteration (ref:225-230, :321): the DUAL

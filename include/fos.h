@@ -266,7 +266,8 @@ int fos_fista_run_backtracking(fos_fista* f, int iters, double eta, double armij
  *   hist     row i  = { unused, ||x||_1, ||x||_2^2, ||x - x_before||^2 } of that iterate (iters x 4 doubles)
  *   rr_seen  [i]    = ||A x - b||^2 of the iterate the iteration STARTED from (it comes out of the gradient pass - DUAL
  *                     kernel - or a residual pass of its own in precise mode), i.e. the objective ingredient of the
- *                     previous row; the caller closes the last row with one fos_residual_objective.
+ *                     previous row; the caller closes the last row with one fos_residual_objective.  NULL: not wanted
+ *                     (ista's log needs x, t and ||dx|| only) - the gradient pass is then the plain one.
  * Rows of iterations that did not complete (stop, parked search) are not written; status.k says how many did.
  * Enqueues only. */
 int fos_fista_run_recorded(fos_fista* f, int iters, int backtracking, double eta, double armijo_c, double grad_eps,

@@ -1239,3 +1239,25 @@ def test_device_driven_backtracking_equals_host_driven(fos, tag):
     xd = fos.fista_delta(prob, None, "lasso", 0.1 * lam, 0.0, 3.0, max_iter=25, L=L, backtracking=True, t_init_factor=2.0)
     assert _data.rel(xd, orc.fista_delta(A, b, "lasso", 0.1 * lam, 0.0, 3.0, max_iter=25, L=L, backtracking=True,
                                          t_init_factor=2.0)) < TOL
+
+
+def test_fused_ista_log_is_recorded_on_the_device(fos):
+    """ista(return_history=True) on a streaming-size problem: x, t and ||dx|| of every iteration are recorded by the
+    device-driven loop (fixed step and backtracking, with the delta < tol stop), equal to the oracle's log."""
+    A, b, fx = _data.problem("aligned")
+    x0 = np.random.default_rng(4).standard_normal(A.shape[1]) * 0.01
+    a1 = 0.05 * float(np.max(np.abs(A.T @ b)))
+    L = float(fx["aligned/L"]) + 0.3
+    ls = fos.LeastSquares(A, b, 0.3)
+    assert ls.prob.plan()["resident"] == 0 and ls.prob.plan()["path"] == 0
+    g = lambda z: orc.smooth_value(A, b, z, 0.3)                        # noqa: E731
+    grad = lambda z: orc.gram_gradient(A, z, b, 0.3)[0]                 # noqa: E731
+    prox = lambda v, t: orc.prox_l1(v, t * a1)                          # noqa: E731
+    for kw in (dict(), dict(backtracking=True, t_init_factor=2.0), dict(tol=5e-3), dict(backtracking=True, t_init_factor=4.0, eta=0.7, tol=5e-3)):
+        x, log = fos.ista(x0, ls, ls.grad, fos.L1Prox(a1), L, max_iter=40, return_history=True, **kw)
+        x_ref, log_ref = orc.ista(x0, g, grad, prox, L, max_iter=40, return_history=True, **kw)
+        assert len(log["x"]) == len(log_ref["x"]) and len(log["delta"]) == len(log_ref["delta"]), kw
+        assert _data.rel(x, x_ref) < TOL and np.allclose(log["t"], log_ref["t"], rtol=1e-12), kw
+        # delta = ||x_new - x||: each iterate carries the fp32 pass's ~1e-7 of ||x||, so small deltas agree absolutely
+        assert np.allclose(log["delta"], log_ref["delta"], rtol=1e-5, atol=2e-6 * float(np.linalg.norm(x_ref))), kw
+        assert _data.rel(log["x"][len(log["x"]) // 2], log_ref["x"][len(log_ref["x"]) // 2]) < TOL, kw
