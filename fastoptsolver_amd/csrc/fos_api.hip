@@ -355,7 +355,11 @@ void plan_fused(fos_problem* p, const MenuEntry* e, int nwg_hint) {
   // 16 single-wave workgroups for the one-wave-per-row geometries.
   const int per_cu = e->threads >= 512 ? 1 : e->threads == 256 ? (e->k <= 2 ? 2 : 1) : 1024 / e->threads;
   int nwg = nwg_hint > 0 ? nwg_hint : p->ncu * per_cu;
-  const int64_t min_rows = 2 * (int64_t)e->r;
+  // at least 2 row steps and 32 KiB of rows per workgroup: below that the slab (one row of n floats per workgroup) and the
+  // slab sums rival the rows they cover (20000 x 256: 26 -> 17.5 us per iteration at 32 rows, 4096 x 512 best at 16 rows,
+  // 100000 x 128 at 49-98 rows: profiles/r02_sweep_mid.txt)
+  const int64_t row_bytes = p->n * (p->dtype == FOS_F32 ? 4 : 2);
+  const int64_t min_rows = std::max<int64_t>(2 * (int64_t)e->r, (32768 + row_bytes - 1) / row_bytes);
   if (m < (int64_t)nwg * min_rows) nwg = (int)std::max<int64_t>(1, m / min_rows);
   p->rows_per_wg = (m + nwg - 1) / nwg;
   p->nwg = (int)((m + p->rows_per_wg - 1) / p->rows_per_wg);
@@ -757,7 +761,8 @@ int ensure_dd(fos_problem* p) {
       p->dd_entry = e;
       // fp64 form: two workgroups per CU for every 256-thread geometry (they hold 2 waves per SIMD at most 256 VGPRs each)
       int nwg = p->ncu * (e->threads >= 512 ? 1 : e->threads == 256 ? 2 : 1024 / e->threads);
-      const int64_t min_rows = 2 * (int64_t)e->r;
+      const int64_t row_bytes = p->n * (p->dtype == FOS_F32 ? 4 : 2);
+      const int64_t min_rows = std::max<int64_t>(2 * (int64_t)e->r, (65536 + row_bytes - 1) / row_bytes);   // fp64 slabs
       if (p->m < (int64_t)nwg * min_rows) nwg = (int)std::max<int64_t>(1, p->m / min_rows);
       p->dd_rows_per_wg = (p->m + nwg - 1) / nwg;
       p->dd_nwg = (int)((p->m + p->dd_rows_per_wg - 1) / p->dd_rows_per_wg);
