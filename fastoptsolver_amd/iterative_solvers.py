@@ -282,85 +282,54 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
                 t_k *= eta                                 # ref:195
                 bt_steps += 1
 
-    # Backtracking without a host round trip per iteration: gradient, one matrix-core batch of 16 candidates, the
-    # decision, the update and the bookkeeping are all enqueued (fos_fista_run_backtracking); the host polls every
-    # `check_every` iterations for stops and for a parked search (all 16 candidates rejected: the reference's
-    # step-underflow regime), which it finishes itself before handing the loop back to the device.
-    if (backtracking and history is None and log is None and reducer is None and max_iter > 0
-            and hasattr(st, "run_backtracking")):
-        chunk = max(1, int(check_every or 8))
-        done, ls_t0, device_ok = 0, time.perf_counter(), True
-        while done < max_iter and device_ok:
+    # Everything with data-dependent control runs device-driven too - no host round trip per iteration:
+    #   backtracking (fos_fista_run_backtracking): gradient, one matrix-core batch of 16 candidates, a decision kernel,
+    #     the update with the accepted step, the bookkeeping - all enqueued;
+    #   with history / ista's log (fos_fista_run_recorded; also adaptive restart and the stopping rules without
+    #     backtracking): iterates and their norms recorded per iteration, ||A x - b||^2 of every iterate out of the NEXT
+    #     iteration's gradient pass, the last objective closed by one residual pass.
+    # The host polls every `check_every` iterations for stops and for a parked search (all 16 candidates rejected: the
+    # reference's step-underflow regime), which it finishes itself before handing the loop back to the device.
+    recording = history is not None or log is not None
+    if reducer is None and max_iter > 0 and hasattr(st, "run_recorded") and (recording or backtracking):
+        cap = _HISTORY_CHUNK_BYTES // (8 * prob.n_dev) if recording else max_iter
+        chunk = max(1, min(int(check_every or (16 if recording else 8)), cap))
+        done, started_total, supported, ls_t0 = 0, 0, True, time.perf_counter()
+        rr_seen, norms = [], []                # rr_seen[t]: residual of the iterate iteration t started from
+        as_tensor = like.tensor if hasattr(like, "tensor") else _core.is_tensor(like)    # ista passes x0 itself
+        while done < max_iter:
             todo = min(chunk, max_iter - done)
             ev = gtimer.start()
-            rec = st.run_backtracking(todo, eta, C, grad_eps)
-            if rec is None:
-                device_ok = False
+            if recording:
+                rec = st.run_recorded(todo, backtracking, eta, C, grad_eps, want_rr=history is not None)
+            else:
+                pair = st.run_backtracking(todo, eta, C, grad_eps)
+                rec = None if pair is None else dict(ls=pair[0], taus=pair[1])
+            if rec is None:                                   # this plan has no candidate pass: the host drives
+                supported = False
                 gtimer.pending.clear()
                 break
             s = st.status()                                   # synchronises: k, stop / stall flag
             ran = int(s.k) - done
             stalled = s.stopped == _lib.STOP_LS_STALL
-            gtimer.stop(ev, max(ran + (1 if (stalled or s.stopped == _lib.STOP_GRAD) else 0), 1))
-            ls_call_iters.extend(int(v) for v in rec[0][:ran].cpu().tolist())
-            done += ran
-            if stalled:                                       # finish this iteration's search on the host
-                tau = st.resume_after_stall()
-                refresh_gradient_after_stall()
-                tau, steps = search_on_host(tau, _BATCH)
-                ls_call_iters.append(steps)
-                st.set_tau(tau)
-                st.update()
-                done += 1
-                if st.status().stopped != _lib.STOP_NONE:
-                    break
-            elif s.stopped != _lib.STOP_NONE:
-                break
-        if device_ok:
-            gtimer.flush()
-            ngrad = done + (1 if st.status().stopped == _lib.STOP_GRAD else 0)
-            del grad_call_times[ngrad:]
-            share = (time.perf_counter() - ls_t0) / max(len(ls_call_iters), 1)
-            ls_call_times.extend([share] * len(ls_call_iters))    # the device does not time its phases: equal shares
-            return st
-
-    # History of the configurations with data-dependent control (backtracking, adaptive restart, stopping rules) recorded
-    # on the device as well (fos_fista_run_recorded): iterates and their norms per iteration, ||A x - b||^2 of every
-    # iterate out of the NEXT iteration's gradient pass; the host polls every `check_every` iterations, finishes a parked
-    # search itself, and closes the last objective with one residual pass.
-    if (history is not None or log is not None) and reducer is None and max_iter > 0 and hasattr(st, "run_recorded"):
-        chunk = max(1, min(int(check_every or 16), _HISTORY_CHUNK_BYTES // (8 * prob.n_dev)))
-        done, started_total, supported, ls_t0 = 0, 0, True, time.perf_counter()
-        rr_seen, norms = [], []                # rr_seen[t]: residual of the iterate iteration t started from
-        while done < max_iter:
-            todo = min(chunk, max_iter - done)
-            ev = gtimer.start()
-            rec = st.run_recorded(todo, backtracking, eta, C, grad_eps, want_rr=history is not None)
-            if rec is None:
-                supported = False
-                gtimer.pending.clear()
-                break
-            s = st.status()                                   # synchronises
-            ran = int(s.k) - done
-            stalled = s.stopped == _lib.STOP_LS_STALL
             started = ran + (1 if (stalled or s.stopped == _lib.STOP_GRAD) else 0)
             gtimer.stop(ev, max(started, 1))
             started_total += started
-            if history is not None:
-                rr_seen.extend(rec["rr_seen"][:started].cpu().tolist())
-            hs = rec["hist"][:ran].cpu().numpy()
-            xh = prob.vec_out(rec["x"][:ran])
-            as_tensor = like.tensor if hasattr(like, "tensor") else _core.is_tensor(like)    # ista passes x0 itself
-            rows = [_core.from_device_vec(xh[i], like) for i in range(ran)] if as_tensor else list(xh.cpu().numpy())
-            if history is not None:
-                history["x"].extend(rows)
-            if log is not None:                                # ista's log (ref:117-120): x, the step used, ||dx||
-                log["x"].extend(rows)
-                log["t"].extend(rec["taus"][:ran].cpu().tolist() if backtracking else [tau] * ran)
-                log["delta"].extend(float(math.sqrt(r[3])) for r in hs)
-            norms.extend((float(r[1]), float(r[2])) for r in hs)
             if backtracking:
                 ls_call_iters.extend(int(v) for v in rec["ls"][:ran].cpu().tolist())
+            if recording:
+                if history is not None:
+                    rr_seen.extend(rec["rr_seen"][:started].cpu().tolist())
+                hs = rec["hist"][:ran].cpu().numpy()
+                xh = prob.vec_out(rec["x"][:ran])
+                rows = [_core.from_device_vec(xh[i], like) for i in range(ran)] if as_tensor else list(xh.cpu().numpy())
+                if history is not None:
+                    history["x"].extend(rows)
+                if log is not None:                            # ista's log (ref:117-120): x, the step used, ||dx||
+                    log["x"].extend(rows)
+                    log["t"].extend(rec["taus"][:ran].cpu().tolist() if backtracking else [tau] * ran)
+                    log["delta"].extend(float(math.sqrt(r[3])) for r in hs)
+                norms.extend((float(r[1]), float(r[2])) for r in hs)
             done += ran
             if stalled:                                       # finish this iteration's search on the host
                 tau = st.resume_after_stall()
@@ -370,14 +339,15 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
                 st.set_tau(tau)
                 st.update()
                 s = st.status()
-                row = _core.from_device_vec(st.x_tensor(), like)
-                if history is not None:
-                    history["x"].append(row)
-                if log is not None:
-                    log["x"].append(row)
-                    log["t"].append(tau)
-                    log["delta"].append(s.this_step)
-                norms.append((s.xnorm1, s.xnorm2))
+                if recording:
+                    row = _core.from_device_vec(st.x_tensor(), like)
+                    if history is not None:
+                        history["x"].append(row)
+                    if log is not None:
+                        log["x"].append(row)
+                        log["t"].append(tau)
+                        log["delta"].append(s.this_step)
+                    norms.append((s.xnorm1, s.xnorm2))
                 done += 1
             if s.stopped != _lib.STOP_NONE:
                 break
@@ -386,7 +356,7 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
             del grad_call_times[started_total:]
             if backtracking:
                 share = (time.perf_counter() - ls_t0) / max(len(ls_call_iters), 1)
-                ls_call_times.extend([share] * len(ls_call_iters))
+                ls_call_times.extend([share] * len(ls_call_iters))    # the device does not time its phases: equal shares
             # f(x after iteration t) needs ||A x - b||^2 of that iterate: seen by iteration t + 1, or by a closing pass
             if history is not None:
                 rr_of = rr_seen[1:done + 1]
