@@ -184,6 +184,14 @@ class Problem:
         _lib.check(self.lib.fos_problem_set_comm(self.h, comm.h if comm is not None else None), "fos_problem_set_comm")
         self.comm = comm               # keeps the communicator alive as long as the problem
 
+    def set_comm_cols(self, comm):
+        """COLUMN sharding: this problem holds A[:, this rank's columns] (all rows) and the whole b; the iterate is
+        partitioned over the ranks (fos_problem_set_comm_cols)."""
+        with self.ctx():
+            _lib.check(self.lib.fos_problem_set_comm_cols(self.h, comm.h), "fos_problem_set_comm_cols")
+        self.comm = comm
+        self.col_sharded = True
+
     def tune(self, threads, chunks, rows, workgroups=0):
         _lib.check(self.lib.fos_problem_tune(self.h, threads, chunks, rows, workgroups), "fos_problem_tune")
 

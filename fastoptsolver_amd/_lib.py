@@ -64,6 +64,7 @@ SIGNATURES = {
     "fos_comm_transport": (C.c_char_p, []),
     "fos_comm_allreduce": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "fos_problem_set_comm": (_i32, [_vp, _vp]),
+    "fos_problem_set_comm_cols": (_i32, [_vp, _vp]),
     "fos_problem_profile": (_i32, [_vp, _i32]),
     "fos_problem_profile_read": (_i32, [_vp, C.POINTER(_f64), C.POINTER(_i64)]),
     "fos_gemv_pair": (_i32, [_vp, _vp, _f32, _vp, _vp]),

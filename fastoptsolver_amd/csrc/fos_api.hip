@@ -258,6 +258,7 @@ struct fos_problem {
   hipStream_t stream = nullptr;
   int ncu = 256;
   fos_comm* comm = nullptr;          // row-sharded problem: sums of partial results go through it (comm.hpp)
+  bool col_sharded = false;          // comm splits the COLUMNS instead: this rank holds A[:, its columns], x is partitioned
   unsigned plan_flags = 0;           // FOS_PLAN_* given to fos_problem_replan
   bool allow_resident = true;
   // plan
@@ -337,6 +338,7 @@ struct fos_fista {
   // precise mode (fos_fista_set_precise): the split-form gradient comes from the fp64-accumulating pass at the unrounded
   // fp64 y_k, so that the Armijo comparison g(x_tmp) <= g(y) + C grad.dlt is decided on fp64-accurate terms
   bool precise = false;
+  double* folded = nullptr;          // column-sharded: the 4 update sums of an iteration, folded and summed over the ranks
   bool tau_on_device = false;        // FistaScalars::tau is authoritative (device-driven backtracking ran since the last set_tau / reset)
   double* gbuf64 = nullptr;          // n + 4 doubles: [gradient ; ||r||^2]
   double* out5 = nullptr;            // device
@@ -466,6 +468,8 @@ int launch_pass(fos_problem* p, const YSource& ys, const float* b, bool with_g, 
   return prof_mark(p, false);
 }
 
+int reduce_across(fos_problem* p, void* buf, size_t count, bool f64);
+
 __global__ __launch_bounds__(256) void sumsq_partials_kernel(const float* __restrict__ v, int64_t m, double* __restrict__ part,
                                                             const int* stopped) {
   if (stopped != nullptr && *stopped != 0) return;
@@ -494,9 +498,15 @@ int launch_pass_colblock(fos_problem* p, const YSource& ys, const float* b, bool
     if (ys.yd) yb.yd = ys.yd + c0;
     yb.res_out = p->rneg;
     yb.res_accum = cb > 0;
-    p->entry->resid_only(Ab + c0 * esz, p->lda, cb == 0 ? b : nullptr, p->m, nb, yb, p->rows_per_wg, p->slabs, p->rr2_part,
+    // column-sharded: b enters the sum over the ranks once (rank 0)
+    const float* b_here = (cb == 0 && !(p->col_sharded && p->comm->rank != 0)) ? b : nullptr;
+    p->entry->resid_only(Ab + c0 * esz, p->lda, b_here, p->m, nb, yb, p->rows_per_wg, p->slabs, p->rr2_part,
                          p->rr2_part, p->nwg, p->stream);
     LAUNCH_CHECK();
+  }
+  if (p->col_sharded) {              // r = sum over the column blocks of ALL ranks: the one m-vector exchange
+    int rc = reduce_across(p, p->rneg, (size_t)p->m, false);
+    if (rc) return rc;
   }
   if (!with_g) {
     hipLaunchKernelGGL(sumsq_partials_kernel, dim3(256), dim3(256), 0, p->stream, p->rneg, p->m, p->rr_part, ys.stopped);
@@ -587,7 +597,7 @@ int launch_slab_reduce_local(fos_problem* p, int n_rr, float* gbuf, double* rr_o
 // slabs -> gbuf[0..n], summed over the ranks when the problem is sharded; rr_out (nullable) = the global ||r||^2
 int launch_slab_reduce(fos_problem* p, int n_rr, float* gbuf, double* rr_out, const int* stopped) {
   int rc = launch_slab_reduce_local(p, n_rr, gbuf, rr_out, stopped);
-  if (rc || !p->comm) return rc;
+  if (rc || !p->comm || p->col_sharded) return rc;      // column-sharded: the gradient block is local, ||r||^2 already global
   if ((rc = reduce_across(p, gbuf, (size_t)p->n + 1, false))) return rc;
   if (rr_out != nullptr) {
     hipLaunchKernelGGL(rr_from_gbuf_kernel, dim3(1), dim3(1), 0, p->stream, gbuf, (int)p->n, rr_out, stopped);
@@ -701,7 +711,7 @@ MultiLaunch find_multi(int64_t n, int nv) {
   return nullptr;
 }
 
-bool batch_supported(const fos_problem* p) { return p->path == 0 && !p->tall; }   // fp32: f32 MFMA; bf16: 3-term bf16 MFMA
+bool batch_supported(const fos_problem* p) { return p->path == 0 && !p->tall && !p->col_sharded; }   // fp32: f32 MFMA; bf16: 3-term bf16 MFMA
 
 // A caller vector the fused prologue can read with 16-byte loads.
 int aligned_vec(fos_problem* p, const float* v, const float** out) {
@@ -953,6 +963,28 @@ int fos_problem_set_comm(fos_problem* p, fos_comm* c) {
   return FOS_OK;
 }
 
+int fos_problem_set_comm_cols(fos_problem* p, fos_comm* c) {
+  if (!p || !c) return fail(FOS_ERR_ARG, "fos_problem_set_comm_cols: null");
+  const int epc = epc_of(p->dtype);
+  const bool vec_ok = (p->n % epc == 0) && (p->lda % epc == 0) && ((reinterpret_cast<uintptr_t>(p->A) & 15u) == 0);
+  if (!vec_ok || p->n <= fos::TL_MAX_N)
+    return fail(FOS_ERR_UNSUPPORTED, "fos_problem_set_comm_cols: needs the streaming layout (aligned, n > 64 per rank)");
+  // the two-phase column-block plan, whatever the width: r = sum_p A_p y_p - b is exchanged between the phases
+  void* drop[] = {p->slabs, p->rr_part, p->rr2_part};
+  for (void* q : drop)
+    if (q) (void)hipFree(q);
+  p->slabs = nullptr; p->rr_part = p->rr2_part = nullptr;
+  p->slab_cap = p->rr_cap = 0;
+  p->tall = false; p->slab_stride = 0; p->vec4 = true; p->resident = false;
+  const int64_t blocks = (p->n + 16383) / 16384;
+  p->cb_width = ((p->n + blocks - 1) / blocks + 63) / 64 * 64;
+  plan_fused(p, default_entry(p->dtype, p->cb_width), 0);
+  p->colblock = true;
+  p->comm = c;
+  p->col_sharded = true;
+  return ensure_workspace(p);
+}
+
 int fos_problem_set_stream(fos_problem* p, void* stream) {
   if (!p) return fail(FOS_ERR_ARG, "fos_problem_set_stream: null");
   hipStream_t ns = reinterpret_cast<hipStream_t>(stream);
@@ -1090,6 +1122,7 @@ int fos_gemv_pair_f64(fos_problem* p, const double* y, double alpha2, float* gra
 // The fp64-accumulating pass for any y source: out[0..n) = A^T (A y - b) + alpha2*l2vec (l2vec may be NULL when alpha2 = 0),
 // out[n] = ||A y - b||^2, summed over the ranks of a sharded problem.  Not for resident-planned problems (callers check).
 static int launch_pass_dd(fos_problem* p, const YSource& ys, double alpha2, const double* l2vec, double* out) {
+  if (p->col_sharded) return fail(FOS_ERR_UNSUPPORTED, "the fp64 pass has no column-sharded form");
   int rc = ensure_dd(p);
   if (rc) return rc;
   int nslabs = 0, n_rr = 0;
@@ -1156,9 +1189,10 @@ int fos_residual_objective(fos_problem* p, const float* x, double* out3) {
   if ((rc = launch_pass(p, ys, p->b, false, &n_rr))) return rc;
   hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->rr_part, n_rr, 1, out3);
   LAUNCH_CHECK();
-  if ((rc = reduce_across(p, out3, 1, true))) return rc;
+  if (!p->col_sharded && (rc = reduce_across(p, out3, 1, true))) return rc;
   hipLaunchKernelGGL(fos::vec_norms_kernel, dim3(1), dim3(fos::LB_THREADS), 0, p->stream, xa, p->n, out3 + 1);
   LAUNCH_CHECK();
+  if (p->col_sharded) return reduce_across(p, out3 + 1, 2, true);     // ||x||^2, ||x||_1 over the column blocks
   return FOS_OK;
 }
 
@@ -1304,7 +1338,7 @@ int fos_fista_create(fos_problem* p, fos_fista** out) {
 
 int fos_fista_destroy(fos_fista* f) {
   if (!f) return FOS_OK;
-  void* bufs[] = {f->x_cur, f->x_prev, f->dlt, f->scal, f->out5, f->part2, f->ynext, f->gbuf64};
+  void* bufs[] = {f->x_cur, f->x_prev, f->dlt, f->scal, f->out5, f->part2, f->ynext, f->gbuf64, f->folded};
   for (void* q : bufs)
     if (q) (void)hipFree(q);
   delete f;
@@ -1381,9 +1415,32 @@ static YSource fista_source(fos_fista* f) {
   return YSource{nullptr, f->x_cur, f->x_prev, &f->scal->beta, &f->scal->stopped, 0.0};
 }
 
+__global__ __launch_bounds__(64) void fold4_kernel(const double* __restrict__ part, int nparts, double* __restrict__ out4,
+                                                   const int* stopped) {
+  if (stopped != nullptr && *stopped != 0) return;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < nparts; i += 64)
+    for (int j = 0; j < 4; ++j) s[j] += part[i * 4 + j];
+  for (int j = 0; j < 4; ++j) s[j] = fos::wave_sum(s[j]);
+  if (threadIdx.x == 0)
+    for (int j = 0; j < 4; ++j) out4[j] = s[j];
+}
+
 static int launch_finalize(fos_fista* f, int n_rr, double* hist_row = nullptr) {
   fos_problem* p = f->p;
-  hipLaunchKernelGGL(fos::fista_finalize_kernel, dim3(1), dim3(64), 0, p->stream, p->part, f->nupd, p->rr_part, n_rr,
+  const double* part = p->part;
+  int nparts = f->nupd;
+  if (p->col_sharded) {
+    // x is partitioned over the ranks: step norms, ||grad||^2, ||x||_1, ||x||^2 are sums over ALL column blocks
+    if (!f->folded) HIP_TRY(hipMalloc(&f->folded, 8 * sizeof(double)));
+    hipLaunchKernelGGL(fold4_kernel, dim3(1), dim3(64), 0, p->stream, p->part, f->nupd, f->folded, &f->scal->stopped);
+    LAUNCH_CHECK();
+    int rc = reduce_across(p, f->folded, 4, true);
+    if (rc) return rc;
+    part = f->folded;
+    nparts = 1;
+  }
+  hipLaunchKernelGGL(fos::fista_finalize_kernel, dim3(1), dim3(64), 0, p->stream, part, nparts, p->rr_part, n_rr,
                      f->scal, f->prm, hist_row);
   LAUNCH_CHECK();
   return FOS_OK;
@@ -1452,6 +1509,17 @@ static bool plain_run(const fos_fista* f) {
 // The gradient-norm stop sits between the reduced gradient and the update (fos_fista_params.tol_grad).
 static int launch_grad_norm_stop(fos_fista* f) {
   fos_problem* p = f->p;
+  if (p->col_sharded) {                        // ||grad||^2 = sum over the column blocks of all ranks
+    if (!f->folded) HIP_TRY(hipMalloc(&f->folded, 8 * sizeof(double)));
+    hipLaunchKernelGGL(fos::grad_norm_stop_kernel, dim3(1), dim3(1024), 0, p->stream, grad_src(f), (int)p->n, f->x_cur,
+                       f->x_prev, f->scal, f->prm, f->folded + 4);
+    LAUNCH_CHECK();
+    int rc = reduce_across(p, f->folded + 4, 1, true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fos::grad_norm_decide_kernel, dim3(1), dim3(1), 0, p->stream, f->folded + 4, f->scal, f->prm);
+    LAUNCH_CHECK();
+    return FOS_OK;
+  }
   hipLaunchKernelGGL(fos::grad_norm_stop_kernel, dim3(1), dim3(1024), 0, p->stream, grad_src(f), (int)p->n, f->x_cur, f->x_prev,
                      f->scal, f->prm);
   LAUNCH_CHECK();
@@ -1771,7 +1839,7 @@ int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters) {
   fos_problem* p = fs[0]->p;
   bool all_plain = true;
   for (int v = 0; v < nv; ++v) all_plain = all_plain && plain_run(fs[v]);
-  const bool streaming = p->path == 0 && !p->tall && !p->colblock && !p->resident && all_plain;
+  const bool streaming = p->path == 0 && !p->tall && !p->colblock && !p->resident && !p->col_sharded && all_plain;
   // (a sharded problem takes the matrix-core pass for any number of weights: its 16 gradients are one 16 x n all-reduce)
   MultiLaunch fn = (streaming && !p->comm && p->dtype == FOS_F32 && p->entry != &kWideF32) ? find_multi(p->n, nv) : nullptr;
   // the two-product pass costs about two single-vector passes per iteration whatever the number of weights: it pays
@@ -1864,7 +1932,7 @@ int fos_fista_grad(fos_fista* f) {
     LAUNCH_CHECK();
     return FOS_OK;
   }
-  const YSource ys = (plain_run(f) && f->host_valid) ? plain_source(f) : fista_source(f);
+  const YSource ys = (plain_run(f) && f->host_valid && !p->col_sharded) ? plain_source(f) : fista_source(f);
   if ((rc = launch_pass(p, ys, p->b, true, &n_rr))) return rc;
   return launch_slab_reduce(p, n_rr, p->gbuf, &f->scal->rr, &f->scal->stopped);
 }
@@ -1880,7 +1948,7 @@ int fos_fista_grad_dual(fos_fista* f) {
     hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->rr2_part, n_rr, 1,
                        &f->scal->rr_x);
     LAUNCH_CHECK();
-    return reduce_across(p, &f->scal->rr_x, 1, true);
+    return p->col_sharded ? FOS_OK : reduce_across(p, &f->scal->rr_x, 1, true);
   }
   // no DUAL instantiation (fallback path / wide geometries): a separate residual pass on x_k, then the gradient
   hipLaunchKernelGGL(fos::cast_f64_f32_kernel, dim3(grid_1d(p->n, 256, 1024)), dim3(256), 0, p->stream, f->x_cur, p->ybuf,
@@ -1891,14 +1959,14 @@ int fos_fista_grad_dual(fos_fista* f) {
   hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->rr_part, n_rr, 1,
                      &f->scal->rr_x);
   LAUNCH_CHECK();
-  if ((rc = reduce_across(p, &f->scal->rr_x, 1, true))) return rc;
+  if (!p->col_sharded && (rc = reduce_across(p, &f->scal->rr_x, 1, true))) return rc;
   return fos_fista_grad(f);
 }
 
 int fos_fista_update(fos_fista* f) {
   if (!f) return fail(FOS_ERR_ARG, "fos_fista_update: null");
   fos_problem* p = f->p;
-  const bool plain = plain_run(f) && f->host_valid;
+  const bool plain = plain_run(f) && f->host_valid && !p->col_sharded;
   double* part = p->part;
   int host_beta = 0;
   double beta_k = 0.0, beta_next = 0.0;
@@ -1937,6 +2005,7 @@ int fos_fista_update(fos_fista* f) {
 int fos_fista_trial(fos_fista* f, double t, int with_residual, double out8[8]) {
   if (!f || !out8 || !(t > 0.0)) return fail(FOS_ERR_ARG, "fos_fista_trial: bad argument");
   fos_problem* p = f->p;
+  if (p->col_sharded) return fail(FOS_ERR_UNSUPPORTED, "fos_fista_trial: no column-sharded form (||A dlt||^2 needs an m-vector exchange per candidate)");
   { int rcf = flush_pending(f); if (rcf) return rcf; }
   const int grid = grid_1d(p->n, 256, 256);
   HIP_TRY(hipMemsetAsync(f->out5, 0, 8 * sizeof(double), p->stream));

@@ -453,10 +453,13 @@ __global__ void fista_init_scalars_kernel(FistaScalars* __restrict__ scal) {
 // Gradient-norm stop (iterative_solvers.py:179: `if tol > 0 and ||grad|| < tol: break`, checked BEFORE the update, grad of
 // the smooth part at y_k incl. alpha2*y) on the device, so that fista(tol > 0) stays enqueue-only: one workgroup reads the
 // reduced gradient in gbuf and raises the stop flag; the update and finalize kernels behind it are then no-ops.
+// partial_out != nullptr (column-sharded problems): only this rank's sum of squares is written; after the sum over the
+// ranks grad_norm_decide_kernel takes the decision.
 __global__ __launch_bounds__(1024) void grad_norm_stop_kernel(GradSrc gsrc, int n,
                                                              const double* __restrict__ x_cur,
                                                              const double* __restrict__ x_prev,
-                                                             FistaScalars* __restrict__ scal, FistaParams prm) {
+                                                             FistaScalars* __restrict__ scal, FistaParams prm,
+                                                             double* __restrict__ partial_out = nullptr) {
   if (scal->stopped != 0) return;
   __shared__ double ws[16];
   const double beta = scal->beta;
@@ -472,9 +475,15 @@ __global__ __launch_bounds__(1024) void grad_norm_stop_kernel(GradSrc gsrc, int 
   if (threadIdx.x == 0) {
     double s = 0.0;
     for (int i = 0; i < 16; ++i) s += ws[i];
+    if (partial_out != nullptr) { *partial_out = s; return; }
     scal->gnorm2 = s;
     if (sqrt(s) < prm.tol_grad) scal->stopped = STOP_GRAD;
   }
+}
+__global__ void grad_norm_decide_kernel(const double* __restrict__ total, FistaScalars* __restrict__ scal, FistaParams prm) {
+  if (scal->stopped != 0) return;
+  scal->gnorm2 = *total;
+  if (sqrt(*total) < prm.tol_grad) scal->stopped = STOP_GRAD;
 }
 
 // Device-side Armijo decision (iterative_solvers.py:187-195 for the candidates t, t*eta, ... of one matrix-core batch):

@@ -534,11 +534,42 @@ def ista(x0, g, grad_g, prox_h, L, backtracking: bool = False, eta: float = 0.5,
     return (out, log) if return_history else out
 
 
-def _sharded_problem(A, b, dtype, comm, group):
+def _lipschitz_cols(prob, comm, cols, n_iter=100, tol=1e-6):
+    """estimate_lipschitz (ref:45-60) for a column-sharded matrix: v is partitioned like x; w_p = A_p^T (sum_q A_q v_q) is
+    the two-phase pass with its one m-vector exchange, ||w|| sums the blocks' squares over the ranks.  Draws the n_total
+    normals of ref:50 from the global stream on every rank (same seed everywhere) and keeps this rank's slice."""
+    lo, hi, n_total = cols
+    v = torch.from_numpy(np.random.randn(n_total)[lo:hi].copy()).to(prob.device, torch.float32)
+    bare = prob if prob.b is None else None
+    if bare is None:
+        bare = _core.Problem(prob.A, None, prob.dtype, pad=False)               # same A, b = 0 (ref:54)
+        bare.set_comm_cols(comm)
+    nrm = lambda t: math.sqrt(float(comm.allreduce((t.double() @ t.double()).reshape(1))[0]))   # noqa: E731
+    v = v / nrm(v)
+    prev, L = 0.0, None
+    for _ in range(n_iter):
+        w = bare.gemv_pair(v, 0.0)
+        L = nrm(w)
+        v = w / L
+        if abs(L - prev) < tol:
+            break
+        prev = L
+    return L
+
+
+def _sharded_problem(A, b, dtype, comm, group, cols=None):
     """(problem, reducer) for the solver front-ends: plain, Comm-attached (reductions under the C ABI, reducer None)
-    or split-form over a torch.distributed group (reducer does the sums)."""
+    or split-form over a torch.distributed group (reducer does the sums).  cols = (lo, hi, n_total): COLUMN sharding -
+    A holds this rank's columns [lo, hi) of an m x n_total matrix, b is whole, the returned x is this rank's block."""
     if comm is None and group is None:
         return _core.as_problem(A, b, dtype), None
+    if cols is not None:
+        if comm is None:
+            raise ValueError("column sharding needs a distributed.Comm (comm=)")
+        prob = A if isinstance(A, _core.Problem) else _core.Problem(A, b, dtype, pad=False)
+        if not getattr(prob, "col_sharded", False):
+            prob.set_comm_cols(comm)
+        return prob, None
     import torch.distributed as dist
     prob = A if isinstance(A, _core.Problem) else _core.Problem(A, b, dtype, pad=True)   # same n_dev on every rank
     if comm is not None:
@@ -556,15 +587,25 @@ def _sharded_problem(A, b, dtype, comm, group):
 def fista(A, b, reg_type: str, alpha1: float, alpha2: float, backtracking: bool = False, eta: float = 0.5,
           t_init_factor: float = 1.0, max_iter: int = 500, tol: float = 0.0, tol_ratio: float = 0.0,
           adaptive_restart: bool = False, restart_threshold: float = 1.0, return_history: bool = False,
-          *, L=None, dtype=None, check_every=None, comm=None, group=None):
+          *, L=None, dtype=None, check_every=None, comm=None, group=None, cols=None):
     """``comm=`` / ``group=``: A, b are THIS RANK's rows of a row-sharded problem (one process per GPU); every flag
     of the reference's loop works sharded - backtracking, history, restart, the stopping rules.  ``comm`` (a
     `distributed.Comm`) puts the one all-reduce per iteration on the kernels' stream under the C ABI; ``group`` (a
-    torch.distributed group, any backend) does it between the kernels from Python."""
+    torch.distributed group, any backend) does it between the kernels from Python.
+    ``cols=(lo, hi, n_total)`` with ``comm=``: COLUMN sharding for very wide A - A is this rank's columns [lo, hi) of
+    all rows, b the whole vector; x is partitioned (the result and the history are this rank's block), one all-reduce of
+    an m-vector per iteration; no backtracking in this form."""
     reset_metrics()
-    prob, reducer = _sharded_problem(A, b, dtype, comm, group)
+    prob, reducer = _sharded_problem(A, b, dtype, comm, group, cols)
     like = prob.like
-    L_val = estimate_lipschitz(prob, group=group if reducer is not None else None) if L is None else float(L)   # ref:155
+    if cols is not None and backtracking:
+        raise NotImplementedError("backtracking has no column-sharded form (||A dlt||^2 needs an m-vector per candidate)")
+    if L is not None:
+        L_val = float(L)
+    elif cols is not None:
+        L_val = _lipschitz_cols(prob, comm, cols)
+    else:
+        L_val = estimate_lipschitz(prob, group=group if reducer is not None else None)                        # ref:155
     if alpha2 > 0:                                                            # ref:156-157
         L_val += alpha2
     tau = t_init_factor / L_val                                               # ref:158
@@ -587,13 +628,20 @@ def fista(A, b, reg_type: str, alpha1: float, alpha2: float, backtracking: bool 
 def fista_delta(A, b, reg_type: str, alpha1: float, alpha2: float, delta: float, backtracking: bool = False,
                 eta: float = 0.5, t_init_factor: float = 1.0, max_iter: int = 500, tol: float = 0.0,
                 tol_ratio: float = 0.0, return_history: bool = False, *, L=None, dtype=None, check_every=None,
-                comm=None, group=None):
+                comm=None, group=None, cols=None):
     reset_metrics()
     # Course requirement: delta > 2 for convergence guarantee                   ref:268
     assert delta > 2, "In FISTA-Δ, delta must be > 2 for convergence (course requirement)"
-    prob, reducer = _sharded_problem(A, b, dtype, comm, group)
+    prob, reducer = _sharded_problem(A, b, dtype, comm, group, cols)
     like = prob.like
-    L_val = estimate_lipschitz(prob, group=group if reducer is not None else None) if L is None else float(L)   # ref:273
+    if cols is not None and backtracking:
+        raise NotImplementedError("backtracking has no column-sharded form (||A dlt||^2 needs an m-vector per candidate)")
+    if L is not None:
+        L_val = float(L)
+    elif cols is not None:
+        L_val = _lipschitz_cols(prob, comm, cols)
+    else:
+        L_val = estimate_lipschitz(prob, group=group if reducer is not None else None)                        # ref:273
     if alpha2 > 0:
         L_val += alpha2
     tau = t_init_factor / L_val

@@ -132,6 +132,15 @@ const char* fos_comm_transport(void);
 /* In-place sum over the ranks of `count` floats (is_f64 = 0) or doubles (1) on `stream`; enqueues only. */
 int fos_comm_allreduce(fos_comm* c, void* buf, int64_t count, int is_f64, void* stream);
 int fos_problem_set_comm(fos_problem* p, fos_comm* c);
+/* COLUMN sharding (very wide A: SURVEY.md 8f rank 4): every rank binds A[:, its columns] (all m rows, n_p columns) and
+ * the whole b; the iterate is PARTITIONED - a rank owns and updates only its block of x, nothing is replicated.  The
+ * pass becomes two phases around ONE exchange of an m-vector: r = sum_p A_p y_p - b (all-reduce of m floats), then
+ * g_p = A_p^T r locally; prox and momentum are separable, so the update is local; the four scalar sums of an iteration
+ * (step norms, ||grad||^2, ||x||_1, ||x||^2) are all-reduced (4 doubles) so that restart and the stopping rules decide on
+ * global numbers.  A_p is read twice per iteration (before and after the exchange).  fos_fista_run / _grad / _update,
+ * fos_gemv_pair, fos_residual_objective work on such a problem; the Armijo trials, the fp64 pass, the multi-lambda pass
+ * and the one-launch power iteration do not (FOS_ERR_UNSUPPORTED).  Needs the streaming layout (n_p > 64, 16-byte rows). */
+int fos_problem_set_comm_cols(fos_problem* p, fos_comm* c);
 
 /* Kernel timing for roofline reports: while enabled (enable = N > 0), every N-th launch of the single-pass kernel
  * (or of the two fallback kernels, or of the batched MFMA pass) is bracketed by a pair of hipEvents recorded on the

@@ -326,3 +326,87 @@ def test_one_shot_mesh_allreduce_two_processes(tmp_path):
     for i in range(6):
         a1p, a2p = lam * 0.4 * 0.7 ** i, (0.5 if i % 3 == 1 else 0.0)
         assert _data.rel(r0["xpath"][i], orc.fista(A, b, "elasticnet", a1p, a2p, max_iter=25, L=L)) < TOL, i
+
+
+# --------------------------------------------------------------------------------------------------
+# column sharding (very wide A): x partitioned, one m-vector exchange per iteration
+# --------------------------------------------------------------------------------------------------
+COL_SHAPE = (600, 2048, 13)
+COL_CASES = [dict(), dict(adaptive_restart=True), dict(tol=0.5), dict(tol_ratio=0.9), dict(return_history=True),
+             dict(return_history=True, adaptive_restart=True, tol_ratio=0.97)]
+
+
+def _cols_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import fastoptsolver_amd as fos
+    from fastoptsolver_amd import distributed as fd
+    comm = fd.Comm(dist.group.WORLD, transport="mesh", cap_bytes=1 << 20)
+    A, b, _ = _data.synth(*COL_SHAPE)
+    m, n = A.shape
+    a1, a2 = _weights(A, b)
+    lo, hi = fd.shard_rows(n, world, rank)                  # the same contiguous split, applied to the columns
+    Ad = torch.as_tensor(A.astype(np.float32)).cuda()[:, lo:hi]          # strided view: lda = n
+    prob = fos.prepare(Ad, b.astype(np.float32), pad=False)
+    out = {"lohi": np.asarray([lo, hi])}
+    np.random.seed(0)
+    x = fos.fista(prob, None, "elasticnet", a1, a2, max_iter=5, comm=comm, cols=(lo, hi, n))      # L by power iteration
+    out["x_l"] = x.cpu().numpy()
+    np.random.seed(0)
+    L = orc.estimate_lipschitz(A, v0=np.random.randn(n))
+    for i, kw in enumerate(COL_CASES):
+        res = fos.fista(prob, None, "elasticnet", a1, a2, max_iter=40, L=L, comm=comm, cols=(lo, hi, n), **kw)
+        if kw.get("return_history"):
+            xk, h = res
+            out[f"obj{i}"] = np.asarray(h["obj"])
+            out[f"xmid{i}"] = h["x"][len(h["x"]) // 2].cpu().numpy()
+        else:
+            xk = res
+        out[f"x{i}"] = xk.cpu().numpy()
+        out[f"ngrad{i}"] = np.asarray(fos.get_metrics()["grad_num_calls"])
+    xd = fos.fista_delta(prob, None, "lasso", a1, 0.0, 3.0, max_iter=30, L=L, comm=comm, cols=(lo, hi, n))
+    out["xd"] = xd.cpu().numpy()
+    try:
+        fos.fista(prob, None, "lasso", a1, 0.0, max_iter=3, L=L, comm=comm, cols=(lo, hi, n), backtracking=True)
+        out["bt_raises"] = np.asarray(False)
+    except NotImplementedError:
+        out["bt_raises"] = np.asarray(True)
+    comm.check()
+    np.savez(os.path.join(out_dir, f"c{rank}.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_column_sharding_two_processes(tmp_path):
+    """A split by COLUMNS over two ranks (each: all rows, half the columns, the whole b): the concatenated blocks of x
+    equal the unsharded oracle for the plain loop, adaptive restart, the three stopping rules (same stopping iteration),
+    the history objective, FISTA-delta, and with L from the column-sharded power iteration."""
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_cols_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"c{k}.npz") for k in range(world)]
+    A, b, _ = _data.synth(*COL_SHAPE)
+    a1, a2 = _weights(A, b)
+    n = A.shape[1]
+    cat = lambda key: np.concatenate([r[k][key] for k in range(world)])       # noqa: E731
+    assert all(bool(rk["bt_raises"]) for rk in r)
+    np.random.seed(0)
+    L = orc.estimate_lipschitz(A, v0=np.random.randn(n))
+    assert _data.rel(cat("x_l"), orc.fista(A, b, "elasticnet", a1, a2, max_iter=5, L=L)) < TOL
+    for i, kw in enumerate(COL_CASES):
+        ref = orc.fista(A, b, "elasticnet", a1, a2, max_iter=40, L=L, **kw)
+        _, met = orc.fista(A, b, "elasticnet", a1, a2, max_iter=40, L=L, return_metrics=True,
+                           **{k: v for k, v in kw.items() if k != "return_history"})
+        x_ref = ref[0] if kw.get("return_history") else ref
+        assert cat(f"x{i}").shape == (n,) and _data.rel(cat(f"x{i}"), x_ref) < TOL, kw
+        assert int(r[0][f"ngrad{i}"]) == int(r[1][f"ngrad{i}"]) == met["grad_num_calls"], kw
+        if kw.get("return_history"):
+            h_ref = ref[1]
+            assert np.array_equal(r[0][f"obj{i}"], r[1][f"obj{i}"]) and len(r[0][f"obj{i}"]) == len(h_ref["obj"]), kw
+            assert np.allclose(r[0][f"obj{i}"], h_ref["obj"], rtol=TOL), kw
+            assert _data.rel(cat(f"xmid{i}"), h_ref["x"][len(h_ref["x"]) // 2]) < TOL, kw
+    assert _data.rel(cat("xd"), orc.fista_delta(A, b, "lasso", a1, 0.0, 3.0, max_iter=30, L=L)) < TOL
