@@ -29,9 +29,9 @@ SHAPES = [
     ("narrow 1000000x128 f32 (one wave per row)", 1000000, 128, "f32", ("f32",)),
     ("narrow 500000x512 f32 (one wave per row)", 500000, 512, "f32", ("f32",)),
     ("1048576x1024 f32", 1048576, 1024, "f32", ("f32", "dd")),
-    ("tall 2000000x64 f32 (row per quad)", 2000000, 64, "f32", ("f32",)),
+    ("tall 2000000x64 f32 (chunk per lane, 16 lanes per row)", 2000000, 64, "f32", ("f32",)),
     ("tall 4000000x16 f32 (row per thread)", 4000000, 16, "f32", ("f32",)),
-    ("tall 4000000x32 f32 (row per thread)", 4000000, 32, "f32", ("f32",)),
+    ("tall 4000000x32 f32 (chunk per lane, 8 lanes per row)", 4000000, 32, "f32", ("f32",)),
     ("tall 8000000x5 f32 (LDS-staged rows)", 8000000, 5, "f32", ("f32",)),
 ]
 

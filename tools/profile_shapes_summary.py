@@ -14,7 +14,7 @@ import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PASS_KERNELS = ("gemv_pair_kernel", "gemv_tall_kernel", "gemv_tall_quad_kernel", "gemv_wide_kernel")
+PASS_KERNELS = ("gemv_pair_kernel", "gemv_tall_kernel", "gemv_tall_quad_kernel", "gemv_tall_rows_kernel", "gemv_wide_kernel")
 
 
 def find(d, pattern):
