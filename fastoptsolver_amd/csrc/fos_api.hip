@@ -211,10 +211,11 @@ const MenuEntry kTallRowsBf16[1] = {TALLR(FOS_BF16, fos::bf16_t, 8)};
 #define TALL(DT, T, NC, LD) \
   { DT, fos::TL_THREADS, 0, 0, tall_launch<T, NC, LD, true, false>, tall_launch<T, NC, LD, false, false>, \
     tall_launch<T, NC, LD, true, true>, tall_launch_dd<T, NC, LD> }
-#define TALL_ROW(DT, T, NC) { TALL(DT, T, NC, fos::TL_DIRECT), TALL(DT, T, NC, fos::TL_VEC), TALL(DT, T, NC, fos::TL_STAGE) }
-const MenuEntry kTallF32[4][3] = {
+#define TALL_ROW(DT, T, NC) \
+  { TALL(DT, T, NC, fos::TL_DIRECT), TALL(DT, T, NC, fos::TL_VEC), TALL(DT, T, NC, fos::TL_STAGE), TALL(DT, T, NC, fos::TL_STAGE4) }
+const MenuEntry kTallF32[4][4] = {
     TALL_ROW(FOS_F32, float, 8), TALL_ROW(FOS_F32, float, 16), TALL_ROW(FOS_F32, float, 32),
-    {TALLQ(FOS_F32, float, false), TALLQ(FOS_F32, float, true), TALLQ(FOS_F32, float, false)}};
+    {TALLQ(FOS_F32, float, false), TALLQ(FOS_F32, float, true), TALLQ(FOS_F32, float, false), TALLQ(FOS_F32, float, false)}};
 const MenuEntry kTallBf16[4][2] = {
     {TALL(FOS_BF16, fos::bf16_t, 8, fos::TL_DIRECT), TALL(FOS_BF16, fos::bf16_t, 8, fos::TL_STAGE)},
     {TALL(FOS_BF16, fos::bf16_t, 16, fos::TL_DIRECT), TALL(FOS_BF16, fos::bf16_t, 16, fos::TL_STAGE)},
@@ -238,7 +239,10 @@ const MenuEntry* tall_entry(int dtype, int64_t n, int64_t lda, const void* A) {
   const bool contiguous = (lda == n);
   if (dtype == FOS_F32) {
     const bool vec = n % 4 == 0 && lda % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15u) == 0;
-    return &kTallF32[idx][vec ? fos::TL_VEC : (contiguous ? fos::TL_STAGE : fos::TL_DIRECT)];
+    // contiguous ragged rows: staged through LDS; float4 copy when the matrix is 16-byte aligned (plan_tall keeps the
+    // rows per workgroup a multiple of 4, so every block then starts on a 16-byte boundary)
+    const bool a16 = (reinterpret_cast<uintptr_t>(A) & 15u) == 0;
+    return &kTallF32[idx][vec ? fos::TL_VEC : (contiguous ? (a16 && idx < 3 ? fos::TL_STAGE4 : fos::TL_STAGE) : fos::TL_DIRECT)];
   }
   return &kTallBf16[idx][contiguous ? 1 : 0];
 }
@@ -379,7 +383,7 @@ void plan_tall(fos_problem* p, const MenuEntry* e) {
   // wave in flight) - profiles/r02_sweep_wgs.log
   const int per_cu = e->k > 0 ? 8 : 4;
   int64_t nwg = std::max<int64_t>(1, std::min<int64_t>(per_cu * (int64_t)p->ncu, p->m / (4 * fos::TL_THREADS)));
-  p->rows_per_wg = (p->m + nwg - 1) / nwg;
+  p->rows_per_wg = ((p->m + nwg - 1) / nwg + 3) / 4 * 4;     // a multiple of 4 rows: 16-byte aligned block starts (staged copy)
   p->nwg = (int)((p->m + p->rows_per_wg - 1) / p->rows_per_wg);
   p->nslabs = p->nwg;
 }
@@ -1061,7 +1065,7 @@ int fos_problem_plan(const fos_problem* p, int32_t plan[8]) {
 int fos_problem_tune(fos_problem* p, int threads, int chunks, int rows, int workgroups) {
   if (!p) return fail(FOS_ERR_ARG, "fos_problem_tune: null");
   if (p->path == 0 && p->tall && workgroups > 0) {        // row-per-thread pass: only the workgroup count is tunable
-    p->rows_per_wg = (p->m + workgroups - 1) / workgroups;
+    p->rows_per_wg = ((p->m + workgroups - 1) / workgroups + 3) / 4 * 4;
     p->nwg = (int)((p->m + p->rows_per_wg - 1) / p->rows_per_wg);
     p->nslabs = p->nwg;
     return ensure_workspace(p);

@@ -12,6 +12,8 @@
 // Output contract = gemv_pair_kernel except for the slab row stride: slabs[wg][tall_slab_stride(n)] (zero padded),
 // rr_part[wg], rr2_part[wg] (DUAL), rows [wg*rows_per_wg, ...).
 #pragma once
+#include <type_traits>
+
 #include "gemv_pair.hpp"
 
 namespace fos {
@@ -27,15 +29,18 @@ __host__ __device__ inline int tall_slab_stride(int n) { return (n + 3) & ~3; }
 //   TL_STAGE   contiguous matrix (lda == n), ragged n: the workgroup copies its 256 x n block of A - one contiguous
 //              span of memory - into LDS with fully coalesced loads, and each thread then reads its row from LDS
 //              (stride n words: conflict-free for odd n); NC <= 32 (LDS budget)
-enum : int { TL_DIRECT = 0, TL_VEC = 1, TL_STAGE = 2 };
+//   TL_STAGE4  TL_STAGE for fp32 with 16-byte aligned block starts (A aligned, rows per workgroup a multiple of 4): the
+//              copy moves float4s - 3 load instructions per thread and block instead of 10 at n = 5
+enum : int { TL_DIRECT = 0, TL_VEC = 1, TL_STAGE = 2, TL_STAGE4 = 3 };
 template <typename T, int NC, int LOAD, bool WITH_G, bool DUAL, typename ST = float>
 __global__ __launch_bounds__(TL_THREADS) void gemv_tall_kernel(const T* __restrict__ A, int64_t lda,
                                                               const float* __restrict__ b, int64_t m, int n, YSource ys,
                                                               int64_t rows_per_wg, ST* __restrict__ slabs,
                                                               double* __restrict__ rr_part, double* __restrict__ rr2_part) {
   constexpr int NW = TL_THREADS / 64;
-  constexpr bool VEC = (LOAD == TL_VEC), STAGE = (LOAD == TL_STAGE);
-  __shared__ float tile_s[STAGE ? (NC <= 16 ? 2 : 1) * TL_THREADS * NC : 1];
+  constexpr bool VEC = (LOAD == TL_VEC), STAGE = (LOAD == TL_STAGE || LOAD == TL_STAGE4), STAGE4 = (LOAD == TL_STAGE4);
+  static_assert(!STAGE4 || sizeof(T) == 4, "TL_STAGE4 is the fp32 form");
+  __shared__ __attribute__((aligned(16))) float tile_s[STAGE ? (NC <= 16 ? 2 : 1) * TL_THREADS * NC : 4];
   __shared__ double y_s[NC];
   __shared__ double x_s[DUAL ? NC : 1];
   __shared__ double red[NW][8];
@@ -62,16 +67,32 @@ __global__ __launch_bounds__(TL_THREADS) void gemv_tall_kernel(const T* __restri
   constexpr int BLOCK_ROWS = RPI * TL_THREADS;
   // TL_STAGE: the block after the one being consumed is already on its way into registers (its global-load latency
   // overlaps the LDS reads and the fp64 arithmetic of this one); it moves into LDS between two barriers.
-  float pre[STAGE ? NC * RPI : 1];
+  constexpr int NPRE = STAGE4 ? (NC * RPI + 3) / 4 : NC * RPI;          // float4s / floats per thread and block
+  typedef typename std::conditional<STAGE4, f32x4, float>::type PreT;
+  PreT pre[STAGE ? NPRE : 1];
   auto prefetch = [&](int64_t row0) {
     if constexpr (STAGE) {
       const int64_t left = row_hi - row0;
       const int count = left <= 0 ? 0 : (int)(left < BLOCK_ROWS ? left : BLOCK_ROWS) * n;
       const T* src = A + row0 * (int64_t)n;                              // lda == n: the block is one contiguous span
 #pragma unroll
-      for (int u = 0; u < NC * RPI; ++u) {
-        const int i = u * TL_THREADS + tid;
-        pre[u] = i < count ? elem_to_float<T>(src[i]) : 0.f;
+      for (int u = 0; u < NPRE; ++u) {
+        if constexpr (STAGE4) {
+          const float* srcf = reinterpret_cast<const float*>(src);
+          const int i = 4 * (u * TL_THREADS + tid);
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (i + 3 < count) {
+            v = *reinterpret_cast<const f32x4*>(srcf + i);
+          } else if (i < count) {                                        // the block's last, partial quad
+            v.x = srcf[i];
+            if (i + 1 < count) v.y = srcf[i + 1];
+            if (i + 2 < count) v.z = srcf[i + 2];
+          }
+          pre[u] = v;
+        } else {
+          const int i = u * TL_THREADS + tid;
+          pre[u] = i < count ? elem_to_float<T>(src[i]) : 0.f;
+        }
       }
     }
   };
@@ -80,9 +101,14 @@ __global__ __launch_bounds__(TL_THREADS) void gemv_tall_kernel(const T* __restri
     if constexpr (STAGE) {
       __syncthreads();                                                   // the previous block has been consumed
 #pragma unroll
-      for (int u = 0; u < NC * RPI; ++u) {
-        const int i = u * TL_THREADS + tid;
-        if (i < BLOCK_ROWS * n) tile_s[i] = pre[u];
+      for (int u = 0; u < NPRE; ++u) {
+        if constexpr (STAGE4) {
+          const int i = 4 * (u * TL_THREADS + tid);
+          if (i < BLOCK_ROWS * n) *reinterpret_cast<f32x4*>(&tile_s[i]) = pre[u];      // BLOCK_ROWS * n is a multiple of 4
+        } else {
+          const int i = u * TL_THREADS + tid;
+          if (i < BLOCK_ROWS * n) tile_s[i] = pre[u];
+        }
       }
       __syncthreads();
       prefetch(row0 + BLOCK_ROWS);
