@@ -235,6 +235,17 @@ def run_workload(name, args, rank, world, device, steps, warmup, want_cpu, dist)
     st = eng.status()
     assert int(st.k) == warmup + steps and st.stopped == 0, (int(st.k), st.stopped)
     assert math.isfinite(st.this_step) and st.this_step > 0.0, "iterate did not move: invalid run"
+    replicas_identical = None
+    if world > 1:
+        # every rank applied the identical update to the identical reduced gradient: the replicated iterates must agree
+        # bit for bit (a transport that delivered different sums to different ranks would show here)
+        xr = eng.x()
+        probe = torch.stack([xr.sum(), xr.abs().sum(), (xr * xr).sum()]).to(torch.float64)
+        hi_, lo_ = probe.clone(), probe.clone()
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        replicas_identical = bool(torch.equal(hi_, lo_))
+        assert replicas_identical, "replicated iterates differ between ranks: invalid run"
 
     b_iter = bytes_per_iter(hi - lo, n, cfg["dtype"])
     kern_us = k_ms * 1e3 / max(k_launches, 1)
@@ -244,7 +255,7 @@ def run_workload(name, args, rank, world, device, steps, warmup, want_cpu, dist)
         achieved_gbps=b_iter / (kern_us * 1e-6) / 1e9 if k_launches else None,
         step_gbps=b_iter / (elapsed / steps) / 1e9, lipschitz_s=lip_s, L=L, alpha1=a1, alpha2=a2,
         plan=eng.prob.plan(), m=m, n=n, rows_per_gpu=hi - lo, dtype=cfg["dtype"], reg=cfg["reg"],
-        final_step_norm=st.this_step)
+        final_step_norm=st.this_step, replicas_identical=replicas_identical)
     cpu, parity = None, None
     if want_cpu and rank == 0 and world == 1:
         cpu, parity = cpu_baseline(cfg, A, b, a1_chk, a2, L, x_check, k_check)
@@ -374,6 +385,7 @@ def main():
                 "iterate_state": "fp64 on device; y rounded once to fp32 for the single pass over A",
                 "backend": backend if world > 1 else None,
                 "rehearsal": bool(args.rows) or (world > 1 and backend != "nccl"),
+                "replicas_identical": res["replicas_identical"],
             },
             "roofline": roofline_obj(res, name if world == 1 else None),
             "cpu_baseline": res["cpu_baseline"],
