@@ -1006,6 +1006,7 @@ int fos_problem_set_stream(fos_problem* p, void* stream) {
 
 int fos_problem_replan(fos_problem* p, unsigned flags) {
   if (!p) return fail(FOS_ERR_ARG, "fos_problem_replan: null");
+  if (p->col_sharded) return fail(FOS_ERR_UNSUPPORTED, "fos_problem_replan: a column-sharded problem keeps its two-phase plan");
   if (flags & ~(unsigned)(FOS_PLAN_NO_RESIDENT | FOS_PLAN_NO_TALL | FOS_PLAN_NO_WIDE | FOS_PLAN_NO_COLBLOCK))
     return fail(FOS_ERR_ARG, "fos_problem_replan: unknown flag");
   // workspace sized for the old plan (slab stride, fp64 slabs) is dropped and rebuilt
@@ -1217,6 +1218,8 @@ int fos_residual_batch(fos_problem* p, const float* X, int nv, int use_b, double
 
 int fos_power_iter(fos_problem* p, float* v_inout, int n_iter, double tol, double* L_out, int* iters_out) {
   if (!p || !v_inout || !L_out || n_iter <= 0) return fail(FOS_ERR_ARG, "fos_power_iter: bad argument");
+  if (p->col_sharded)
+    return fail(FOS_ERR_UNSUPPORTED, "fos_power_iter: column-sharded problems normalise over the ranks (see _lipschitz_cols)");
   if (n_iter + 1 > p->lhist_cap) {             // L after every step (+ the norm of v0): sized by the caller's n_iter
     if (p->lhist) (void)hipFree(p->lhist);
     p->lhist = nullptr;
