@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "../../include/fos.h"
@@ -1161,7 +1162,8 @@ static int launch_pass_dd(fos_problem* p, const YSource& ys, double alpha2, cons
   if ((rc = prof_mark(p, false))) return rc;
   // sharded: alpha2*x enters the sum over the ranks exactly once (rank 0 adds it to its partial)
   const double a2_here = (p->comm && p->comm->rank != 0) ? 0.0 : alpha2;
-  hipLaunchKernelGGL(fos::slab_reduce_dd_kernel, dim3((unsigned)((p->n + 127) / 128)), dim3(256), 0, p->stream, p->slabs_dd,
+  hipLaunchKernelGGL(fos::slab_reduce_dd_kernel, dim3((unsigned)((p->n + fos::SRD_COLS - 1) / fos::SRD_COLS)),
+                     dim3(fos::SRD_THREADS), 0, p->stream, p->slabs_dd,
                      nslabs, (int)p->n, stride, p->rr_dd, n_rr, a2_here, l2vec, out, ys.stopped);
   LAUNCH_CHECK();
   return reduce_across(p, out, (size_t)p->n + 1, true);
@@ -2236,6 +2238,33 @@ int fos_lbfgs_two_loop_dd(const double* g, const double* S, const double* Y, int
   return FOS_OK;
 }
 
+namespace {
+inline int vl_parts(int64_t n) { return (int)std::min<int64_t>((n + fos::VL_COLS - 1) / fos::VL_COLS, fos::VL_MAXPARTS); }
+// d = -H g on the whole chip (lbfgs_kernels.hpp): Gram matrix of the basis, then coefficients + combination
+int launch_direction(const double* g, const double* S, const double* Y, int hist, int head, int cap, int64_t n, double* d_out,
+                     double* gd_out, double* work, hipStream_t st) {
+  const int parts = vl_parts(n);
+  hipLaunchKernelGGL(fos::lbfgs_gram_kernel, dim3(parts), dim3(fos::VL_THREADS), 0, st, g, S, Y, hist, head, std::max(cap, 1),
+                     n, work);
+  const int grid = (int)((n + fos::VL_THREADS - 1) / fos::VL_THREADS);      // one column per thread
+  hipLaunchKernelGGL(fos::lbfgs_combine_kernel, dim3(grid), dim3(fos::VL_THREADS), 0, st, g, S, Y, hist, head,
+                     std::max(cap, 1), n, (const double*)work, parts, d_out, gd_out);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+}  // namespace
+
+int64_t fos_lbfgs_direction_work(int64_t n) { return n > 0 ? (int64_t)vl_parts(n) * fos::VL_PSTRIDE : 0; }
+
+int fos_lbfgs_direction_dd(const double* g, const double* S, const double* Y, int hist, int head, int cap, int64_t n,
+                           double* d_out, double* gd_out, double* work, int64_t work_doubles, void* stream) {
+  if (!g || !d_out || !work || n <= 0 || hist < 0 || cap < hist || (hist > 0 && (!S || !Y)) || head < 0 ||
+      (cap > 0 && head >= cap) || work_doubles < fos_lbfgs_direction_work(n))
+    return fail(FOS_ERR_ARG, "fos_lbfgs_direction_dd: bad argument");
+  if (hist > fos::VL_MAXH) return fail(FOS_ERR_UNSUPPORTED, "fos_lbfgs_direction_dd: at most 10 pairs (fos_lbfgs_two_loop_dd takes 64)");
+  return launch_direction(g, S, Y, hist, head, cap, n, d_out, gd_out, work, (hipStream_t)stream);
+}
+
 int fos_vec_stats_dd(const double* x, const double* g, const double* d, int64_t n, double* out5, void* stream) {
   if (!out5 || n <= 0) return fail(FOS_ERR_ARG, "fos_vec_stats_dd: bad argument");
   hipLaunchKernelGGL((fos::vec_stats_kernel<double, double>), dim3(1), dim3(fos::LB_THREADS), 0, (hipStream_t)stream, x, g,
@@ -2262,11 +2291,11 @@ double fos_linesearch_step(fos_linesearch* ls, double stp, double f, double d) {
 namespace {
 // device + pinned workspace of one fos_lbfgs_minimize call, released on every exit path
 struct LbfgsWork {
-  double *g = nullptr, *g_old = nullptr, *d = nullptr, *x_old = nullptr, *S = nullptr, *Y = nullptr, *stats = nullptr;
+  double *g = nullptr, *g_old = nullptr, *d = nullptr, *x_old = nullptr, *S = nullptr, *Y = nullptr, *vl = nullptr;
   double* host = nullptr;              // pinned: 8 doubles
   std::vector<hipEvent_t> ev;
   ~LbfgsWork() {
-    void* bufs[] = {g, g_old, d, x_old, S, Y, stats};
+    void* bufs[] = {g, g_old, d, x_old, S, Y, vl};
     for (void* q : bufs)
       if (q) (void)hipFree(q);
     if (host) (void)hipHostFree(host);
@@ -2290,23 +2319,34 @@ int fos_lbfgs_minimize(fos_problem* p, double alpha2, int max_iter, double pgtol
   HIP_TRY(hipMalloc(&w.x_old, nb));
   HIP_TRY(hipMalloc(&w.S, nb * M));
   HIP_TRY(hipMalloc(&w.Y, nb * M));
-  HIP_TRY(hipMalloc(&w.stats, 8 * sizeof(double)));
-  HIP_TRY(hipHostMalloc(&w.host, 8 * sizeof(double)));
+  HIP_TRY(hipMalloc(&w.vl, (size_t)fos_lbfgs_direction_work(n) * sizeof(double)));
+  HIP_TRY(hipHostMalloc(&w.host, 16 * sizeof(double)));
+  // The scalars of an evaluation cross to the host in pinned memory the kernels write themselves (no copy engine on the
+  // round trip):  [0..4] x.x, g.d, d.d, max|g|, ||x||_1   [5] ||r||^2   [6] g.d and [7] d.d of the newest direction
+  // [8] sequence number of the evaluation, stored last (system-scope release): the host polls it rather than waiting for
+  // the stream to drain, and falls back to hipStreamSynchronize when it has not appeared after a few milliseconds.
+  double* host_dev = nullptr;
+  HIP_TRY(hipHostGetDevicePointer((void**)&host_dev, w.host, 0));
+  unsigned long long* flag_host = reinterpret_cast<unsigned long long*>(w.host + 8);
+  unsigned long long* flag_dev = reinterpret_cast<unsigned long long*>(host_dev + 8);
+  *flag_host = 0;
+  unsigned long long seq = 0;
+  auto wait_fg = [&]() -> int {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spin = 0;; ++spin) {
+      if (__atomic_load_n(flag_host, __ATOMIC_ACQUIRE) == seq) return FOS_OK;
+      if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(4)) break;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    if (__atomic_load_n(flag_host, __ATOMIC_ACQUIRE) != seq) return fail(FOS_ERR_HIP, "fos_lbfgs_minimize: evaluation did not report");
+    return FOS_OK;
+  };
   const int ax_grid = grid_1d(n, 256, 1024);
   int nfev = 0;
   double xnorm1 = 0.0;
 
-  // host scalars of one evaluation: [x.x, g.d, d.d, max|g|, ||x||_1, ||r||^2]
-  auto read_stats = [&](const double* xv, const double* gv, const double* dv, bool with_rr) -> int {
-    hipLaunchKernelGGL((fos::vec_stats_kernel<double, double>), dim3(1), dim3(fos::LB_THREADS), 0, st, xv, gv, dv, n, w.stats);
-    LAUNCH_CHECK();
-    HIP_TRY(hipMemcpyAsync(w.host, w.stats, 5 * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (with_rr) HIP_TRY(hipMemcpyAsync(w.host + 5, gv + n, sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return FOS_OK;
-  };
-  // loss and gradient at xv (lbfgs.py:43-54), plus g.d for the line search when dv is given
-  auto fg = [&](const double* xv, double* gv, const double* dv, double* loss, double* gd, double* gmax) -> int {
+  // loss and gradient at xv (lbfgs.py:43-54) plus g.d for the line search: enqueue only ...
+  auto enqueue_fg = [&](const double* xv, double* gv, const double* dv) -> int {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (fg_ms && nfev < fg_cap) {
       HIP_TRY(hipEventCreate(&e0));
@@ -2318,13 +2358,19 @@ int fos_lbfgs_minimize(fos_problem* p, double alpha2, int max_iter, double pgtol
     int rc = fos_gemv_pair_dd(p, xv, alpha2, gv);
     if (rc) return rc;
     if (e1) HIP_TRY(hipEventRecord(e1, st));
-    if ((rc = read_stats(xv, gv, dv, true))) return rc;
+    seq += 1;
+    hipLaunchKernelGGL((fos::vec_stats_kernel<double, double>), dim3(1), dim3(fos::LB_THREADS), 0, st, xv, (const double*)gv,
+                       dv, n, host_dev, (const double*)(gv + n), flag_dev, seq);
+    LAUNCH_CHECK();
+    return FOS_OK;
+  };
+  // ... and take its scalars once the stream has drained
+  auto take_fg = [&](double* loss, double* gd, double* gmax) {
     nfev += 1;
     *loss = 0.5 * w.host[5] + 0.5 * alpha2 * w.host[0];
     *gd = w.host[1];
     *gmax = w.host[3];
     xnorm1 = w.host[4];
-    return FOS_OK;
   };
   auto axpby = [&](double a, const double* xv, double b, const double* yv, double* out) {
     hipLaunchKernelGGL(fos::vec_axpby_f64_kernel<double>, dim3(ax_grid), dim3(256), 0, st, a, xv, b, b != 0.0 ? yv : nullptr,
@@ -2346,31 +2392,47 @@ int fos_lbfgs_minimize(fos_problem* p, double alpha2, int max_iter, double pgtol
   double *g = w.g, *g_old = w.g_old;
   int hist_n = 0, head = 0, nit = 0;
   double f = 0.0, gd = 0.0, gmax = 0.0;
-  int rc = fg(x, g, nullptr, &f, &gd, &gmax);
+  int rc = enqueue_fg(x, g, nullptr);
   if (rc) return rc;
+  if ((rc = wait_fg())) return rc;
+  take_fg(&f, &gd, &gmax);
   if (gmax <= pgtol) return finish(f, gmax, 0, 0);
   for (;;) {
-    // direction d = -H g (two-loop recursion over the stored pairs)
+    // direction d = -H g (two-loop recursion over the stored pairs); the kernel leaves g.d and d.d in host[6..7]
     const bool vec = (n % 4 == 0);
 #define FOS_TL(NQ) hipLaunchKernelGGL((fos::lbfgs_two_loop_kernel<double, NQ>), dim3(1), dim3(fos::LB_THREADS), 0, st, \
-                                      (const double*)g, (const double*)w.S, (const double*)w.Y, hist_n, head, M, n, w.d)
-    if (vec && n <= 4096) FOS_TL(1);
-    else if (vec && n <= 8192) FOS_TL(2);
-    else if (vec && n <= 16384) FOS_TL(4);
+                                      (const double*)g, (const double*)w.S, (const double*)w.Y, hist_n, head, M, n, w.d, \
+                                      host_dev + 6)
+    if (n >= 2048) {                            // whole-chip form: two launches, each one read of the history
+      if ((rc = launch_direction(g, w.S, w.Y, hist_n, head, M, n, w.d, host_dev + 6, w.vl, st))) return rc;
+    } else if (vec) FOS_TL(1);
     else FOS_TL(0);
 #undef FOS_TL
     LAUNCH_CHECK();
-    if ((rc = read_stats(nullptr, g, w.d, false))) return rc;
-    const double gd0 = w.host[1], dd = w.host[2];
-    if (gd0 >= 0.0) {                           // not a descent direction: drop the memory (L-BFGS-B info = -4)
+    // The first trial step is known without looking at the direction (1 after the first iteration: L-BFGS-B's rule), so
+    // the trial point and its evaluation are enqueued behind the two-loop kernel and ONE host round trip serves both.
+    double stp = 1.0;
+    if (nit == 0) {
+      HIP_TRY(hipStreamSynchronize(st));
+      if (w.host[6] >= 0.0) return finish(f, gmax, nit, 3);          // not a descent direction and no memory to drop
+      stp = std::min(1.0 / std::sqrt(w.host[7]), 1e10);
+    }
+    hipLaunchKernelGGL(fos::lbfgs_first_trial_kernel, dim3(ax_grid), dim3(256), 0, st, x, (const double*)w.d, stp, w.x_old, n);
+    LAUNCH_CHECK();
+    std::swap(g, g_old);                        // g_old holds the gradient at x_old; g receives the trial gradients
+    const size_t ev_mark = w.ev.size();
+    if ((rc = enqueue_fg(x, g, w.d))) return rc;
+    if ((rc = wait_fg())) return rc;
+    const double gd0 = w.host[6];
+    const double f_old = f, gmax_old = gmax;
+    if (gd0 >= 0.0) {                           // not a descent direction: drop the memory (L-BFGS-B info = -4);
+      HIP_TRY(hipMemcpyAsync(x, w.x_old, nb, hipMemcpyDeviceToDevice, st));   // the speculative evaluation never happened
+      std::swap(g, g_old);
+      while (w.ev.size() > ev_mark) { (void)hipEventDestroy(w.ev.back()); w.ev.pop_back(); }
       if (hist_n == 0) return finish(f, gmax, nit, 3);
       hist_n = 0; head = 0;
       continue;
     }
-    double stp = nit == 0 ? std::min(1.0 / std::sqrt(dd), 1e10) : 1.0;
-    HIP_TRY(hipMemcpyAsync(w.x_old, x, nb, hipMemcpyDeviceToDevice, st));
-    std::swap(g, g_old);                        // g_old holds the gradient at x_old; g receives the trial gradients
-    const double f_old = f, gmax_old = gmax;
     fos_linesearch ls{};
     stp = fos_ls_begin_impl(&ls, stp, f_old, gd0);
     int evals = 0;
@@ -2378,9 +2440,13 @@ int fos_lbfgs_minimize(fos_problem* p, double alpha2, int max_iter, double pgtol
     double gd1 = gd0, stp_used = stp;
     for (;;) {
       if (evals >= MAXLS) { failed = true; break; }
-      axpby(1.0, w.x_old, stp, w.d, x);         // x = stp*d + x_old, products and sum rounded separately (NumPy's)
-      LAUNCH_CHECK();
-      if ((rc = fg(x, g, w.d, &f, &gd1, &gmax))) return rc;
+      if (evals > 0) {
+        axpby(1.0, w.x_old, stp, w.d, x);       // x = stp*d + x_old, products and sum rounded separately (NumPy's)
+        LAUNCH_CHECK();
+        if ((rc = enqueue_fg(x, g, w.d))) return rc;
+        if ((rc = wait_fg())) return rc;
+      }
+      take_fg(&f, &gd1, &gmax);
       evals += 1;
       stp_used = stp;
       stp = fos_ls_step_impl(&ls, stp, f, gd1);
@@ -2396,20 +2462,27 @@ int fos_lbfgs_minimize(fos_problem* p, double alpha2, int max_iter, double pgtol
     }
     stp = stp_used;
     if (hist) { hist[2 * nit] = f; hist[2 * nit + 1] = xnorm1; }
-    if (iterates) HIP_TRY(hipMemcpyAsync(iterates + (size_t)nit * n, x, nb, hipMemcpyDeviceToDevice, st));
+    {                                           // record the iterate; keep the pair only if its curvature is positive
+      const double sy = (gd1 - gd0) * stp;
+      const bool keep_pair = sy > EPS * (-gd0 * stp);
+      int slot = 0;
+      if (keep_pair) {
+        slot = (head + hist_n) % M;
+        if (hist_n == M) head = (head + 1) % M;
+        else hist_n += 1;
+      }
+      if (keep_pair || iterates) {
+        hipLaunchKernelGGL(fos::lbfgs_store_pair_kernel, dim3(ax_grid), dim3(256), 0, st, stp, (const double*)w.d,
+                           (const double*)g, (const double*)g_old, keep_pair ? w.S + (size_t)slot * n : nullptr,
+                           keep_pair ? w.Y + (size_t)slot * n : nullptr, (const double*)x,
+                           iterates ? iterates + (size_t)nit * n : nullptr, n);
+        LAUNCH_CHECK();
+      }
+    }
     nit += 1;
     if (nit >= max_iter) return finish(f, gmax, nit, 2);
     if (gmax <= pgtol) return finish(f, gmax, nit, 0);
     if ((f_old - f) <= EPS * FACTR * std::max(std::max(std::fabs(f_old), std::fabs(f)), 1.0)) return finish(f, gmax, nit, 1);
-    const double sy = (gd1 - gd0) * stp;
-    if (sy > EPS * (-gd0 * stp)) {              // keep the pair only if its curvature is positive
-      const int slot = (head + hist_n) % M;
-      if (hist_n == M) head = (head + 1) % M;
-      else hist_n += 1;
-      axpby(stp, w.d, 0.0, nullptr, w.S + (size_t)slot * n);             // s = stp * d
-      axpby(1.0, g, -1.0, g_old, w.Y + (size_t)slot * n);                // y = g - g_old
-      LAUNCH_CHECK();
-    }
   }
 }
 

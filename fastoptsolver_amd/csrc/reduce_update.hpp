@@ -204,24 +204,27 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 }
 
 // fp64 slabs (fos_gemv_pair_dd, the L-BFGS fg): out[j] = sum_s slabs[s][j] + alpha2*y[j] in fp64, fixed order;
-// out[n] = sum of the rr partials.  One thread per column pair (16-byte loads), 256 columns per workgroup... the slabs
-// are nslabs x stride doubles (stride >= n).  grid = ceil(n / 128), 256 threads = 64 column pairs x 4 slab groups.
-__global__ __launch_bounds__(256) void slab_reduce_dd_kernel(const double* __restrict__ slabs, int nslabs, int n,
-                                                            int64_t stride, const double* __restrict__ rr_part, int n_rr,
-                                                            double alpha2, const double* __restrict__ y,
-                                                            double* __restrict__ out, const int* stopped = nullptr) {
+// out[n] = sum of the rr partials.  The slabs are nslabs x stride doubles (stride >= n) - 512 x 8192 x 8 B = 32 MiB at
+// config 3 - so the sum is spread wide: a workgroup owns 64 columns, 512 threads = 32 column pairs (16-byte loads) x 16
+// slab groups, each group sums every 16th slab and the groups are added in index order.  grid = ceil(n / 64).
+constexpr int SRD_GROUPS = 16, SRD_COLS = 64, SRD_THREADS = SRD_GROUPS * SRD_COLS / 2;
+__global__ __launch_bounds__(SRD_THREADS) void slab_reduce_dd_kernel(const double* __restrict__ slabs, int nslabs, int n,
+                                                                    int64_t stride, const double* __restrict__ rr_part,
+                                                                    int n_rr, double alpha2, const double* __restrict__ y,
+                                                                    double* __restrict__ out, const int* stopped = nullptr) {
   if (stopped != nullptr && *stopped != 0) return;
-  __shared__ double lds[4][128];
-  const int pair = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int col = blockIdx.x * 128 + 2 * pair;
+  __shared__ double lds[SRD_GROUPS][SRD_COLS];
+  const int pair = threadIdx.x & (SRD_COLS / 2 - 1), grp = threadIdx.x / (SRD_COLS / 2);
+  const int col = blockIdx.x * SRD_COLS + 2 * pair;
   double a0 = 0.0, a1 = 0.0;
   if (col + 1 < n && (stride & 1) == 0) {
-    for (int s = grp; s < nslabs; s += 4) {
+#pragma unroll 4
+    for (int s = grp; s < nslabs; s += SRD_GROUPS) {
       const f64x2 v = *reinterpret_cast<const f64x2*>(slabs + (int64_t)s * stride + col);
       a0 += v.x; a1 += v.y;
     }
   } else if (col < n) {
-    for (int s = grp; s < nslabs; s += 4) {
+    for (int s = grp; s < nslabs; s += SRD_GROUPS) {
       a0 += slabs[(int64_t)s * stride + col];
       if (col + 1 < n) a1 += slabs[(int64_t)s * stride + col + 1];
     }
@@ -229,16 +232,18 @@ __global__ __launch_bounds__(256) void slab_reduce_dd_kernel(const double* __res
   lds[grp][2 * pair] = a0;
   lds[grp][2 * pair + 1] = a1;
   __syncthreads();
-  if (threadIdx.x < 128) {
-    const int c = blockIdx.x * 128 + threadIdx.x;
+  if (threadIdx.x < SRD_COLS) {
+    const int c = blockIdx.x * SRD_COLS + threadIdx.x;
     if (c < n) {
-      double tot = (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
+      double tot = lds[0][threadIdx.x];
+#pragma unroll
+      for (int g = 1; g < SRD_GROUPS; ++g) tot += lds[g][threadIdx.x];
       if (alpha2 != 0.0) tot += alpha2 * y[c];
       out[c] = tot;
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x >= 192) {      // the last wave folds the rr partials (fixed order)
-    const int l = threadIdx.x - 192;
+  if (blockIdx.x == 0 && threadIdx.x >= SRD_THREADS - 64) {      // the last wave folds the rr partials (fixed order)
+    const int l = threadIdx.x - (SRD_THREADS - 64);
     double s = 0.0;
     for (int i = l; i < n_rr; i += 64) s += rr_part[i];
     s = wave_sum(s);

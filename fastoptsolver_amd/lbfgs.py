@@ -141,7 +141,8 @@ class LBFGSSolver:
         grad_call_times.extend(float(fg_ms[i]) * 1e-3 for i in range(min(self.nfev_, cap)))
         l1 = self.reg_type in ("lasso", "elasticnet")
         self.history_.extend(hist[2 * k] + (self.alpha1 * hist[2 * k + 1] if l1 else 0.0) for k in range(self.nit_))
-        self.iterates_ = [ops.to_caller(iterates[k]) for k in range(self.nit_)] if keep else []
+        # one conversion (and one copy to the host for ndarray callers) for all iterates; the list holds its rows
+        self.iterates_ = list(ops.to_caller(iterates[: self.nit_])) if keep and self.nit_ else []
         self.x_ = ops.to_caller(x)                                                    # lbfgs.py:71
         self.final_obj_ = float(res.f)                                                # lbfgs.py:72
         return self

@@ -305,6 +305,15 @@ int fos_vec_axpby_f64(double a, const double* x, double b, const float* y, doubl
  * (any alignment works, through the generic form). */
 int fos_lbfgs_two_loop_dd(const double* g, const double* S, const double* Y, int hist, int head, int cap, int64_t n,
                           double* d_out, void* stream);
+/* The same direction d = -H g computed by the whole chip in two launches (the two-loop chain above is bound to ONE
+ * workgroup: 35 us at n = 8192 and 10 pairs, 0.9 ms at n = 65536): the Gram matrix of {s_i, y_i, g} by many workgroups,
+ * then the recursion on 2*hist+1 coefficients and d as their combination (L-BFGS-B's own compact representation; equal to
+ * the two-loop result in exact arithmetic, ~1e-13 relative in fp64).  hist <= 10 (FOS_ERR_UNSUPPORTED beyond).
+ * gd_out (device or pinned host memory, may be NULL) receives { g.d, d.d }.  work: fos_lbfgs_direction_work(n) doubles of
+ * device scratch.  This is what fos_lbfgs_minimize runs for n >= 2048. */
+int64_t fos_lbfgs_direction_work(int64_t n);
+int fos_lbfgs_direction_dd(const double* g, const double* S, const double* Y, int hist, int head, int cap, int64_t n,
+                           double* d_out, double* gd_out, double* work, int64_t work_doubles, void* stream);
 int fos_vec_stats_dd(const double* x, const double* g, const double* d, int64_t n, double* out5, void* stream);
 /* out = a*x + b*y with the two products and the sum rounded separately (no fma contraction): bit for bit NumPy's
  * `stp * d + x_old`, `g - g_old`, `stp * d` (oracle lbfgs_minimize). */

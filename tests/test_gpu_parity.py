@@ -360,6 +360,47 @@ def test_two_loop_kernel_vs_oracle(fos):
         assert _data.rel(d64.cpu().numpy(), d_ref) < 1e-12, (n, hist)
 
 
+def test_whole_chip_direction_vs_two_loop_and_oracle(fos):
+    """fos_lbfgs_direction_dd (Gram matrix + coefficient recursion on many CUs) against the one-workgroup two-loop
+    kernel and the oracle: the direction to 1e-12, g.d and d.d to 1e-11, for every history length / ring position and
+    for lengths from below one chunk to many chunks per workgroup."""
+    import ctypes as C
+    from fastoptsolver_amd import _core, _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    cases = [(8192, 10, 10, 3), (8192, 10, 10, 0), (1000, 4, 10, 0), (37, 0, 10, 0), (16385, 7, 10, 8), (129, 1, 10, 9),
+             (70001, 10, 10, 5), (2048, 3, 4, 2)]
+    for n, hist, cap, head in cases:
+        S = rng.standard_normal((cap, n))
+        Y = S + 0.3 * rng.standard_normal((cap, n))                      # s.y > 0
+        g = rng.standard_normal(n)
+        order = [(head + i) % cap for i in range(hist)]
+        d_ref = orc.two_loop_direction(g, [S[i] for i in order], [Y[i] for i in order])
+        S64, Y64, g64 = _dev(S, torch.float64), _dev(Y, torch.float64), _dev(g, torch.float64)
+        d_tl = torch.empty(n, dtype=torch.float64, device="cuda")
+        _lib.check(lib.fos_lbfgs_two_loop_dd(_core.ptr(g64), _core.ptr(S64), _core.ptr(Y64), hist, head, cap, n,
+                                             _core.ptr(d_tl), _core.stream_ptr()))
+        nwork = lib.fos_lbfgs_direction_work(n)
+        work = torch.empty(nwork, dtype=torch.float64, device="cuda")
+        d = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        gd = torch.zeros(2, dtype=torch.float64, device="cuda")
+        _lib.check(lib.fos_lbfgs_direction_dd(_core.ptr(g64), _core.ptr(S64), _core.ptr(Y64), hist, head, cap, n,
+                                              _core.ptr(d), _core.ptr(gd), _core.ptr(work), nwork, _core.stream_ptr()))
+        dn = d.cpu().numpy()
+        assert _data.rel(dn, d_ref) < 1e-12, (n, hist)
+        assert _data.rel(dn, d_tl.cpu().numpy()) < 1e-12, (n, hist)
+        gdn = gd.cpu().numpy()
+        assert gdn[0] == pytest.approx(float(g @ d_ref), rel=1e-11), (n, hist)
+        assert gdn[1] == pytest.approx(float(d_ref @ d_ref), rel=1e-11), (n, hist)
+    # more than 10 pairs: the one-workgroup kernel's job; too little scratch is refused
+    rc = lib.fos_lbfgs_direction_dd(_core.ptr(g64), _core.ptr(S64), _core.ptr(Y64), 11, 0, 11, n, _core.ptr(d),
+                                    None, _core.ptr(work), nwork, _core.stream_ptr())
+    assert rc == -4
+    rc = lib.fos_lbfgs_direction_dd(_core.ptr(g64), _core.ptr(S64), _core.ptr(Y64), 3, 0, 4, n, _core.ptr(d),
+                                    None, _core.ptr(work), 8, _core.stream_ptr())
+    assert rc == -1
+
+
 # --------------------------------------------------------------------------------------------------
 # stopping rules, restart, tensor I/O
 # --------------------------------------------------------------------------------------------------

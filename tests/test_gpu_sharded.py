@@ -374,6 +374,14 @@ def _cols_worker(rank, world, port, out_dir):
         out["bt_raises"] = np.asarray(False)
     except NotImplementedError:
         out["bt_raises"] = np.asarray(True)
+    from fastoptsolver_amd import _lib
+    refused = 0
+    for call in (lambda: prob.replan(no_colblock=True), lambda: prob.power_iter(np.ones(hi - lo, np.float32), 3)):
+        try:
+            call()
+        except _lib.FosError:
+            refused += 1
+    out["refused"] = np.asarray(refused)
     comm.check()
     np.savez(os.path.join(out_dir, f"c{rank}.npz"), **out)
     dist.barrier()
@@ -394,6 +402,7 @@ def test_column_sharding_two_processes(tmp_path):
     n = A.shape[1]
     cat = lambda key: np.concatenate([r[k][key] for k in range(world)])       # noqa: E731
     assert all(bool(rk["bt_raises"]) for rk in r)
+    assert all(int(rk["refused"]) == 2 for rk in r)          # replan / local power iteration refuse partial sums
     np.random.seed(0)
     L = orc.estimate_lipschitz(A, v0=np.random.randn(n))
     assert _data.rel(cat("x_l"), orc.fista(A, b, "elasticnet", a1, a2, max_iter=5, L=L)) < TOL
