@@ -13,6 +13,7 @@
 
 #include "../../include/fos.h"
 #include "batch_trial.hpp"
+#include "cluster_pass.hpp"
 #include "comm.hpp"
 #include "gemv_multi.hpp"
 #include "gemv_pair.hpp"
@@ -315,6 +316,14 @@ struct fos_problem {
   int64_t panel_rows = 0;
   int gram_splits = 0;
   int64_t gram_rows_per_split = 0;
+  // one-read form of the same pass (cluster_pass.hpp): hand-off ring, flags, launch epoch
+  int cp_cs = 0, cp_clusters = 0;    // members per cluster (0: shape not served), clusters
+  int64_t cp_rows_per_cluster = 0;
+  float* cp_xchg = nullptr;
+  unsigned* cp_flags = nullptr;
+  int* cp_error = nullptr;
+  unsigned cp_epoch = 1;
+  bool cp_on = false;                // FOS_PLAN_CLUSTER (opt-in)
   // optional kernel timing (fos_problem_profile)
   int profiling = 0;                 // 0 off, N: bracket every N-th launch of the A pass
   int64_t prof_seq = 0;
@@ -798,6 +807,37 @@ int ensure_dd(fos_problem* p) {
 
 }  // namespace
 
+namespace {
+// One launch of the one-read multi-lambda pass (cluster_pass.hpp); cooperative: all members of a cluster must be resident.
+template <int CS>
+int launch_cluster_pass_cs(fos_problem* p) {
+  auto kern = fos::cluster_pass_kernel<CS>;
+  static std::atomic<uint64_t> done{0};
+  if (raise_dynamic_lds(kern, fos::CP_LDS_BYTES, done)) return fail(FOS_ERR_HIP, "cluster pass: dynamic LDS size refused");
+  const float* A = (const float*)p->A;
+  int64_t lda = p->lda, m = p->m, rpc = p->cp_rows_per_cluster, n_stride = p->n;
+  int n = (int)p->n, n_pad = (int)p->n_pad, xcd_aware = 1;
+  const float* b = p->b;
+  const float* xp = p->xp;
+  unsigned epoch = p->cp_epoch;
+  void* args[] = {&A, &lda, &b, &m, &n, &n_pad, &xp, &rpc, &xcd_aware, &p->cp_xchg, &p->cp_flags, &epoch, &p->slabs16, &n_stride,
+                  &p->cp_error};
+  HIP_TRY(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kern), dim3((unsigned)(p->cp_clusters * CS)),
+                                     dim3(fos::CP_THREADS), args, (unsigned)fos::CP_LDS_BYTES, p->stream));
+  p->cp_epoch += (unsigned)(rpc / fos::CP_ROWS) + 16u;
+  return FOS_OK;
+}
+int launch_cluster_pass(fos_problem* p) {
+  switch (p->cp_cs) {
+    case 4: return launch_cluster_pass_cs<4>(p);
+    case 8: return launch_cluster_pass_cs<8>(p);
+    case 16: return launch_cluster_pass_cs<16>(p);
+  }
+  return fail(FOS_ERR_STATE, "cluster pass: no plan");
+}
+
+}  // namespace
+
 extern "C" {
 
 const char* fos_last_error(void) { return g_err.c_str(); }
@@ -1008,8 +1048,18 @@ int fos_problem_set_stream(fos_problem* p, void* stream) {
 int fos_problem_replan(fos_problem* p, unsigned flags) {
   if (!p) return fail(FOS_ERR_ARG, "fos_problem_replan: null");
   if (p->col_sharded) return fail(FOS_ERR_UNSUPPORTED, "fos_problem_replan: a column-sharded problem keeps its two-phase plan");
-  if (flags & ~(unsigned)(FOS_PLAN_NO_RESIDENT | FOS_PLAN_NO_TALL | FOS_PLAN_NO_WIDE | FOS_PLAN_NO_COLBLOCK))
+  if (flags & ~(unsigned)(FOS_PLAN_NO_RESIDENT | FOS_PLAN_NO_TALL | FOS_PLAN_NO_WIDE | FOS_PLAN_NO_COLBLOCK | FOS_PLAN_CLUSTER))
     return fail(FOS_ERR_ARG, "fos_problem_replan: unknown flag");
+  // the multi-lambda workspace follows its own plan (one-read cluster form or two products): rebuilt on first use
+  {
+    void* multi[] = {p->rbuf16, p->slabs16, p->cp_xchg, p->cp_flags, p->cp_error};
+    for (void* q : multi)
+      if (q) (void)hipFree(q);
+    p->rbuf16 = p->slabs16 = p->cp_xchg = nullptr; p->cp_flags = nullptr; p->cp_error = nullptr;
+    p->cp_cs = p->cp_clusters = 0;
+    p->cp_on = (flags & FOS_PLAN_CLUSTER) != 0;
+    flags &= ~(unsigned)FOS_PLAN_CLUSTER;
+  }
   // workspace sized for the old plan (slab stride, fp64 slabs) is dropped and rebuilt
   void* drop[] = {p->slabs, p->rr_part, p->rr2_part, p->slabs_dd, p->rr_dd};
   for (void* q : drop)
@@ -1044,7 +1094,8 @@ int fos_problem_destroy(fos_problem* p) {
   if (!p) return FOS_OK;
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   void* bufs[] = {p->slabs, p->rr_part, p->rr2_part, p->rvec, p->gbuf_own, p->ybuf, p->dscal, p->part, p->xp, p->q_part, p->bt_out,
-                  p->slabs_dd, p->rr_dd, p->lhist, p->rbuf16, p->slabs16, p->rneg, p->zeros};
+                  p->slabs_dd, p->rr_dd, p->lhist, p->rbuf16, p->slabs16, p->rneg, p->zeros, p->cp_xchg, p->cp_flags,
+                  p->cp_error};
   for (void* q : bufs)
     if (q) (void)hipFree(q);
   delete p;
@@ -1059,7 +1110,7 @@ int fos_problem_plan(const fos_problem* p, int32_t plan[8]) {
   plan[3] = p->entry ? p->entry->r : 0;
   plan[4] = p->nwg;
   plan[5] = p->nslabs;
-  plan[6] = (p->path == 0 ? 1 : 0) | (p->resident ? 2 : 0) | (p->tall ? 4 : 0) | (p->colblock ? 8 : 0);
+  plan[6] = (p->path == 0 ? 1 : 0) | (p->resident ? 2 : 0) | (p->tall ? 4 : 0) | (p->colblock ? 8 : 0) | (p->cp_cs ? 16 : 0);
   plan[7] = p->ncu;
   return FOS_OK;
 }
@@ -1733,6 +1784,23 @@ static int run_multi_mfma(fos_fista* const* fs, int nv, int iters) {
   if (rc) return rc;
   const bool is_bf16 = p->dtype == FOS_BF16;
   const int64_t esz = is_bf16 ? 2 : 4;
+  // One-read form (cluster_pass.hpp), on request (FOS_PLAN_CLUSTER): fp32, 2049..16384 columns in strips of 1024 -> 4, 8
+  // or 16 members per cluster, all CUs busy, at least 8 panels per cluster.  Anything else takes the two-product form
+  // below, which is also the default: the hand-off chain of the cluster form is exposed under HBM load.
+  if (!p->rbuf16 && p->cp_on && !is_bf16 && p->ncu % 8 == 0) {
+    const int cs_need = (int)((p->n + fos::CP_W - 1) / fos::CP_W);
+    const int cs = cs_need <= 2 ? 0 : cs_need <= 4 ? 4 : cs_need <= 8 ? 8 : cs_need <= 16 ? 16 : 0;
+    if (cs && (p->ncu / 8) % cs == 0 && p->m >= (int64_t)(p->ncu / cs) * fos::CP_ROWS * 8) {
+      p->cp_cs = cs;
+      p->cp_clusters = p->ncu / cs;
+      p->cp_rows_per_cluster = ((p->m + p->cp_clusters - 1) / p->cp_clusters + fos::CP_ROWS - 1) / fos::CP_ROWS * fos::CP_ROWS;
+      HIP_TRY(hipMalloc(&p->cp_xchg, (size_t)p->ncu * fos::CP_SLOTS * 256 * sizeof(float)));
+      HIP_TRY(hipMalloc(&p->cp_flags, (size_t)p->ncu * fos::CP_FLAG_STRIDE * sizeof(unsigned)));
+      HIP_TRY(hipMemsetAsync(p->cp_flags, 0, (size_t)p->ncu * fos::CP_FLAG_STRIDE * sizeof(unsigned), p->stream));
+      HIP_TRY(hipMalloc(&p->cp_error, sizeof(int)));
+      HIP_TRY(hipMemsetAsync(p->cp_error, 0, sizeof(int), p->stream));
+    }
+  }
   if (!p->rbuf16) {
     // Panel: product 1 gives a workgroup 64-128 whole rows, so it needs >= 128 * CUs * 2 rows to fill the chip; row
     // splits of product 2: enough (strip, split) workgroups for two per CU.  (A panel that fits the Infinity Cache
@@ -1744,6 +1812,7 @@ static int run_multi_mfma(fos_fista* const* fs, int nv, int iters) {
     splits = std::min<int64_t>(splits, std::max<int64_t>(1, p->panel_rows / 256));
     p->gram_rows_per_split = ((p->panel_rows + splits - 1) / splits + fos::GB_ROWS - 1) / fos::GB_ROWS * fos::GB_ROWS;
     p->gram_splits = (int)((p->panel_rows + p->gram_rows_per_split - 1) / p->gram_rows_per_split);
+    if (p->cp_cs) p->gram_splits = p->cp_clusters;      // one slab set per cluster
     HIP_TRY(hipMalloc(&p->rbuf16, (size_t)p->panel_rows * fos::BT_NV * sizeof(float)));
     HIP_TRY(hipMalloc(&p->slabs16, (size_t)p->gram_splits * fos::BT_NV * p->n * sizeof(float)));
   }
@@ -1773,6 +1842,9 @@ static int run_multi_mfma(fos_fista* const* fs, int nv, int iters) {
   }
   for (int it = 0; it < iters; ++it) {
     if ((rc = prof_mark(p, true))) return rc;
+    if (p->cp_cs) {
+      if ((rc = launch_cluster_pass(p))) return rc;
+    } else
     for (int64_t row0 = 0, panel = 0; row0 < p->m; row0 += p->panel_rows, ++panel) {
       const int64_t rows = std::min<int64_t>(p->panel_rows, p->m - row0);
       const char* Ap = reinterpret_cast<const char*>(p->A) + (size_t)row0 * p->lda * esz;

@@ -31,7 +31,10 @@ enum { FOS_MODE_FISTA = 0, FOS_MODE_DELTA = 1, FOS_MODE_ISTA = 2 };
 enum { FOS_PROX_L1 = 0, FOS_PROX_ENET = 1 };
 enum { FOS_STOP_NONE = 0, FOS_STOP_STEP = 1, FOS_STOP_RATIO = 2, FOS_STOP_GRAD = 3, FOS_STOP_LS_STALL = 4 };
 
-enum { FOS_PLAN_NO_RESIDENT = 1, FOS_PLAN_NO_TALL = 2, FOS_PLAN_NO_WIDE = 4, FOS_PLAN_NO_COLBLOCK = 8 };   /* fos_problem_replan */
+enum { FOS_PLAN_NO_RESIDENT = 1, FOS_PLAN_NO_TALL = 2, FOS_PLAN_NO_WIDE = 4, FOS_PLAN_NO_COLBLOCK = 8,
+       FOS_PLAN_CLUSTER = 16 };   /* fos_problem_replan; FOS_PLAN_CLUSTER OPTS IN to the one-read cluster form of the
+                                     multi-weight matrix-core pass (csrc/cluster_pass.hpp: cooperative launch, fp32,
+                                     2049..16384 columns; measured 6 % faster at 65536 x 8192, slower at 16384 columns) */
 
 typedef struct fos_problem fos_problem;   /* A, b, launch plan, workspace            */
 typedef struct fos_comm fos_comm;         /* communicator of a row-sharded problem   */
@@ -85,7 +88,8 @@ int fos_problem_set_stream(fos_problem* p, void* stream);
  *               workgroups, slabs, flags (bit 0: non-temporal loads; bit 1: small enough for the single-launch
  *               LDS-resident loop that fos_fista_run / _run_history / fos_power_iter then use; bit 2: n <= 64, the
  *               single pass is the row-per-thread kernel, which has no alignment requirements; bit 3: rows wider than
- *               any single-pass kernel - column blocks through the streaming kernel in two phases, A read twice), CUs} */
+ *               any single-pass kernel - column blocks through the streaming kernel in two phases, A read twice;
+ *               bit 4: set once fos_fista_run_multi has planned the one-read cluster form of the matrix-core pass), CUs} */
 int fos_problem_plan(const fos_problem* p, int32_t plan[8]);
 /* Re-run the planner with kernel families switched off (FOS_PLAN_* bits): NO_RESIDENT keeps small problems off the
  * one-launch LDS-resident loop, NO_TALL keeps n <= 64 off the row-per-thread pass, NO_WIDE keeps 16384 < n <= 32768 off

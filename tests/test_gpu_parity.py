@@ -970,6 +970,36 @@ def test_fista_path_sixteen_weights_on_the_matrix_cores(fos, kind, m, n, nlam):
     assert _data.rel(_np(x_again[0]), _np(xs[0])) < 1e-6
 
 
+@pytest.mark.parametrize("m,n,nlam", [(4133, 8188, 16), (2100, 16384, 11), (8200, 4096, 16), (4200, 5000, 6)])
+def test_fista_path_one_read_cluster_pass(fos, m, n, nlam):
+    """The opt-in one-read form of the matrix-core pass (cluster_pass.hpp: clusters of 4 / 8 / 16 workgroups share row panels,
+    both products from one LDS tile, partial residuals handed over through L2): equal to the two-product form (1e-6: same
+    arithmetic, other summation order) for every weight and to the oracle (1e-5); ragged row counts (masked tail panel),
+    strips that end inside a 1024-column block, members without any column (n = 5000 on 8 members), repeated launches
+    (flag epochs) and bit-reproducibility."""
+    A, b, _ = _data.synth(m, n, 5 + n)
+    At = torch.as_tensor(A.astype(np.float32)).cuda()
+    A = At.to(torch.float64).cpu().numpy()
+    b = b.astype(np.float32).astype(np.float64)
+    prob = fos.prepare(At, b.astype(np.float32))
+    lam = float(np.max(np.abs(A.T @ b)))
+    L = float(np.linalg.norm(A, "fro") ** 2)
+    alphas = [(lam * 0.4 * 0.7 ** i, 0.5 if i % 3 == 1 else 0.0) for i in range(nlam)]
+    xt = fos.fista_path(prob, None, alphas, max_iter=12, L=L)            # default: the two-product form
+    assert prob.plan()["cluster"] == 0
+    prob.replan(cluster=True)
+    xs = fos.fista_path(prob, None, alphas, max_iter=12, L=L)
+    assert prob.plan()["cluster"] == 1
+    xs2 = fos.fista_path(prob, None, alphas, max_iter=12, L=L)
+    for x, x2 in zip(xs, xs2):
+        assert torch.equal(x, x2)
+    for i, (x, x_two) in enumerate(zip(xs, xt)):
+        assert _data.rel(_np(x), _np(x_two)) < 1e-6, i
+    for i in (0, nlam // 2, nlam - 1):
+        a1, a2 = alphas[i]
+        assert _data.rel(_np(xs[i]), orc.fista(A, b, "elasticnet", a1, a2, max_iter=12, L=L)) < TOL, i
+
+
 def test_fista_path_falls_back_on_shapes_without_multi_kernel(fos):
     A, b, fx = _data.problem("ragged")          # two-pass path: no multi-vector kernel -> one by one, same answers
     lam = float(np.max(np.abs(A.T @ b)))
