@@ -101,6 +101,31 @@ def test_random_lbfgs(fos, seed):
         assert _data.rel(s.x_, x_star) < 1e-4      # distance of L-BFGS's own stopping point (factr 1e7) from the optimum
 
 
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FOS_FUZZ_LBFGS_SEEDS", "10"))))
+def test_random_lbfgs_wide(fos, seed):
+    """Longer vectors: the whole-chip direction kernels (n >= 2048: Gram matrix + coefficient recursion), more than one
+    column chunk per workgroup, ragged n (two-pass / padded passes), bf16 storage, the full 10-pair memory with ring
+    wrap-around (25 iterations), the speculative first trial of every iteration - counts, exit and every iterate
+    against the oracle on the stored A."""
+    rng = np.random.default_rng(2500 + seed)
+    n = int(rng.choice([2048, 2052, 3001, 4100, 8192, 16388]))
+    m = int(rng.choice([n // 4, n // 2, n, 2 * n]))
+    kind = str(rng.choice(["f32", "f32", "bf16"]))
+    A = rng.standard_normal((m, n)).astype(np.float32)
+    At = torch.as_tensor(A).to(torch.bfloat16 if kind == "bf16" else torch.float32).cuda()
+    A64 = At.to(torch.float64).cpu().numpy()
+    b32 = rng.standard_normal(m).astype(np.float32)
+    a2 = float(rng.choice([1.0, 30.0, 1000.0]))
+    reg = str(rng.choice(["ridge", "elasticnet"]))
+    s = fos.LBFGSSolver(reg, 0.3, a2, max_iter=25).fit(At, torch.as_tensor(b32).cuda())
+    s_ref = orc.LBFGSSolver(reg, 0.3, a2, max_iter=25).fit(A64, b32.astype(np.float64))
+    assert (s.nit_, s.nfev_, s.task_) == (s_ref.nit_, s_ref.nfev_, s_ref.task_), (seed, m, n, kind, s.task_, s_ref.task_)
+    for i in range(s.nit_):
+        xi = s.iterates_[i].detach().cpu().numpy().astype(np.float64)
+        assert _data.rel(xi, s_ref.iterates_[i]) < 1e-5, (seed, m, n, kind, i)
+    assert np.allclose(s.history_, s_ref.history_, rtol=1e-6), (seed, m, n, kind)
+
+
 _BT_COVERAGE = [0, 0]      # iterations with compared shrink counts / all iterations, over the sweep
 
 
