@@ -267,6 +267,32 @@ def run_workload(name, args, rank, world, device, steps, warmup, want_cpu, dist)
     return res
 
 
+def lbfgs_reference(device):
+    """BASELINE config 3: LBFGSSolver("ridge", 0, 1).fit on the cfg2 matrix (65536 x 8192 fp32), fp64 end to end under the
+    C ABI (fos_lbfgs_minimize).  Warm fit timed on the wall clock; fg = one fp64-accumulating pass over A, priced on
+    B_fg = m*n*4 + 4m + 8n with the HIP-event mean of the passes.  Parity of this exact run (SciPy's nit / nfev,
+    every iterate to 1e-5) is tests/test_gpu_parity.py::test_cfg3_full_size_lbfgs."""
+    import fastoptsolver_amd as fos
+    cfg = WORKLOADS["cfg2"]
+    A, b = make_shard(cfg, 0, cfg["m"], device)
+    prob = fos.prepare(A, b)
+    fos.LBFGSSolver("ridge", 0.0, 1.0).fit(prob, None)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    s = fos.LBFGSSolver("ridge", 0.0, 1.0).fit(prob, None)
+    torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0
+    met = fos.get_metrics()
+    b_fg = cfg["m"] * cfg["n"] * 4 + 4 * cfg["m"] + 8 * cfg["n"]
+    out = dict(workload="cfg3: LBFGSSolver('ridge', 0, 1.0).fit, A 65536x8192 f32 on 1 GPU, fp64 iterate / gradient / line search",
+               nit=int(s.nit_), nfev=int(s.nfev_), task=s.task_, fit_ms=wall * 1e3, iterations_per_second=s.nit_ / wall,
+               fg_device_mean_us=met["grad_time_mean"] * 1e6, fg_algorithmic_bytes=b_fg,
+               fg_roofline_frac=b_fg / met["grad_time_mean"] / (HBM_PEAK_GBPS * 1e9), final_obj=float(s.final_obj_))
+    del prob, A, b
+    torch.cuda.empty_cache()
+    return out
+
+
 def load_traffic(workload):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass (profiles/)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -357,6 +383,14 @@ def main():
         except Exception as exc:      # must not take the headline measurement down with it
             target_ref = dict(error=str(exc)[:200])
 
+    # BASELINE config 3 (L-BFGS, ridge, on the cfg2 matrix) rides along in the default N=1 run as `lbfgs_ref`
+    lbfgs_ref = None
+    if world == 1 and name == "cfg4" and not args.no_target_ref and args.workload is None and not args.rows:
+        try:
+            lbfgs_ref = lbfgs_reference(device)
+        except Exception as exc:
+            lbfgs_ref = dict(error=str(exc)[:200])
+
     if rank == 0:
         cfg = WORKLOADS[name]
         out = {
@@ -395,6 +429,7 @@ def main():
                                "`rows` rows of this workload (same L, alpha1, alpha2); the run aborts above 1e-5"},
             "lipschitz_power_iteration_s": res["lipschitz_s"],
             "target_ref": target_ref,
+            "lbfgs_ref": lbfgs_ref,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
