@@ -77,10 +77,10 @@ int raise_dynamic_lds(K kernel, size_t bytes, std::atomic<uint64_t>& done) {
   return FOS_OK;
 }
 
-template <typename T, int THREADS, int K, int R, int MINW, bool YLDS>
+template <typename T, int THREADS, int K, int R, int MINW, bool YLDS, int NB = 2>
 void fused_launch_dd(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, double* slabs,
                      double* rr_part, int nwg, hipStream_t st) {
-  auto kern = fos::gemv_pair_kernel<T, THREADS, K, R, true, MINW, true, 2, false, false, false, double, YLDS>;
+  auto kern = fos::gemv_pair_kernel<T, THREADS, K, R, true, MINW, true, NB, false, false, false, double, YLDS>;
   constexpr size_t lds = YLDS ? (size_t)THREADS * K * fos::ElemTraits<T>::EPC * sizeof(double) : 0;
   if constexpr (lds > 65536) {
     static std::atomic<uint64_t> done{0};
@@ -98,17 +98,22 @@ struct MenuEntry {
 // Streaming geometries of the fp64-accumulating pass, ordered by capacity.  y and the gradient slice cost two VGPRs
 // per column here, so the wide rows take 512 threads x 8 chunks (2 waves per SIMD, 256 VGPRs) instead of 1024 x 4.
 struct DdEntry { int dtype, threads, k, r; FusedLaunchDD fn; };
-#define DD_ENTRY(DT, T, TH, K, R, YL) { DT, TH, K, R, fused_launch_dd<T, TH, K, R, 2, YL> }
+// three register tiles in flight where that measured faster (same-run ratio to the fp32 kernel, tools/bench_dd.py:
+// (512,4) fp32 0.96 -> 0.99, bf16 (256,4) 0.77 -> 0.83, bf16 (512,4) 0.77 -> 0.80; the 256-thread fp32 geometries lost
+// 2-3 % and the (512,8) fp32 geometry would spill: those keep two)
+#define DD_ENTRY(DT, T, TH, K, R, YL) { DT, TH, K, R, fused_launch_dd<T, TH, K, R, 2, YL, 2> }
+#define DD_ENTRY3(DT, T, TH, K, R, YL) { DT, TH, K, R, fused_launch_dd<T, TH, K, R, 2, YL, 3> }
 const DdEntry kDdMenu[] = {
     DD_ENTRY(FOS_F32, float, 64, 1, 4, false), DD_ENTRY(FOS_F32, float, 64, 2, 2, false),
     DD_ENTRY(FOS_F32, float, 256, 1, 2, false), DD_ENTRY(FOS_F32, float, 256, 2, 2, false),
-    DD_ENTRY(FOS_F32, float, 256, 4, 1, false), DD_ENTRY(FOS_F32, float, 512, 4, 1, false),
+    DD_ENTRY(FOS_F32, float, 256, 4, 1, false), DD_ENTRY3(FOS_F32, float, 512, 4, 1, false),
     DD_ENTRY(FOS_F32, float, 512, 8, 1, true),
     DD_ENTRY(FOS_BF16, fos::bf16_t, 64, 1, 2, false), DD_ENTRY(FOS_BF16, fos::bf16_t, 256, 1, 2, false),
-    DD_ENTRY(FOS_BF16, fos::bf16_t, 256, 2, 1, false), DD_ENTRY(FOS_BF16, fos::bf16_t, 256, 4, 1, true),
-    DD_ENTRY(FOS_BF16, fos::bf16_t, 512, 4, 1, true),
+    DD_ENTRY(FOS_BF16, fos::bf16_t, 256, 2, 1, false), DD_ENTRY3(FOS_BF16, fos::bf16_t, 256, 4, 1, true),
+    DD_ENTRY3(FOS_BF16, fos::bf16_t, 512, 4, 1, true),
 };
 #undef DD_ENTRY
+#undef DD_ENTRY3
 #define ENTRY(DT, T, TH, K, R, W) \
   { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, 2, false>, fused_launch<T, TH, K, R, W, false, 2, false>, nullptr }
 // NB register tiles in flight (profiles/r01_kbench_exp_*.log: 3 tiles are worth 1.5 % at n = 8192); D: with DUAL
