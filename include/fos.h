@@ -338,8 +338,12 @@ double fos_linesearch_begin(fos_linesearch* ls, double stp, double f0, double d0
 double fos_linesearch_step(fos_linesearch* ls, double stp, double f, double d);
 
 /* The whole unbounded L-BFGS-B iteration of lbfgs.py:63-70 (SciPy defaults m = 10, factr = 1e7, maxls = 20; maxiter and
- * pgtol from the caller) as ONE call: fg = fos_gemv_pair_dd, direction = the fp64 two-loop kernel, the line search above
- * on the host, all vectors fp64 on the device; the host reads 6 scalars per fg evaluation and nothing else.
+ * pgtol from the caller) as ONE call: fg = fos_gemv_pair_dd, direction = fos_lbfgs_direction_dd (n >= 2048) or the fp64
+ * two-loop kernel, the line search above on the host, all vectors fp64 on the device.  ONE host round trip per fg
+ * evaluation: the first trial point of an iteration (step 1 after the first iteration, L-BFGS-B's rule) and its
+ * evaluation are enqueued together with the direction, the 8 scalars involved (loss terms, g.d, max|g|, ||x||_1 and the
+ * direction's g.d, d.d) arrive in pinned host memory written by the kernels, behind a sequence flag the host polls; a
+ * direction that turns out not to descend discards that evaluation (it is not counted in nfev).
  *   x         device, n doubles: start point in, solution out                                   lbfgs.py:63, :71
  *   hist      host, 2*max_iter doubles (nullable): after iteration k, hist[2k] = loss of fg at x_k, hist[2k+1] = ||x_k||_1
  *             (the callback's compute_objective(x_k) = loss + alpha1*||x_k||_1 without an extra pass)   lbfgs.py:56-61
