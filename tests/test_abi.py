@@ -27,6 +27,11 @@ def test_header_matches_binding_table(lib):
     assert header_symbols() == sorted(_lib.SIGNATURES), "include/fos.h and _lib.SIGNATURES disagree"
 
 
+def test_integration_doc_names_every_entry_point():
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert [s for s in header_symbols() if s not in doc] == []
+
+
 def test_every_symbol_exported(lib):
     from fastoptsolver_amd import _lib
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
