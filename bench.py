@@ -90,13 +90,40 @@ def cpu_threads():
         return os.cpu_count() or 1
 
 
+def cpu_topology():
+    """Host cores as BASELINE.md section 4 asks for them: logical CPUs this process may run on, the physical cores behind
+    them (distinct thread-sibling sets), and the BLAS thread count NumPy will actually use."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except Exception:
+        allowed = list(range(os.cpu_count() or 1))
+    cores = set()
+    for c in allowed:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as fh:
+                cores.add(fh.read().strip())
+        except Exception:
+            cores.add(str(c))
+    blas = None
+    try:
+        from threadpoolctl import threadpool_info
+        info = [i for i in threadpool_info() if i.get("user_api") == "blas"]
+        if info:
+            blas = dict(threads=int(max(i["num_threads"] for i in info)), library=str(info[0].get("internal_api")),
+                        version=str(info[0].get("version")))
+    except Exception:
+        pass
+    return dict(logical=len(allowed), physical=len(cores), os_cpu_count=os.cpu_count(), blas=blas)
+
+
 SAMPLE_ROWS = 65536     # rows of the CPU-baseline / parity sample (the whole of cfg2; the first 65536 rows of cfg4 / cfg5)
 
 
 def cpu_baseline(cfg, A_dev, b_dev, a1, a2, L, x_gpu_k, k_check, budget_s=25.0):
     """The oracle (NumPy fp64, all host cores through BLAS) on a bounded sample of the same workload.  x_gpu_k: the
-    device's iterate after k_check iterations on the SAME sample (same rows, same L, alpha1, alpha2) - the parity
-    figure of the bench line is its relative distance to the oracle's iterate k_check."""
+    device's iterate after k_check iterations on the SAME sample (same rows, same L - the SAMPLE's own Lipschitz
+    estimate, so that tau is the step the reference would take on it and the iterate really moves - alpha1, alpha2);
+    the parity figure of the bench line is its relative distance to the oracle's iterate k_check."""
     from oracle import fos_oracle as orc
     m, n = cfg["m"], cfg["n"]
     rows = min(m, SAMPLE_ROWS)
@@ -124,12 +151,15 @@ def cpu_baseline(cfg, A_dev, b_dev, a1, a2, L, x_gpu_k, k_check, budget_s=25.0):
               f"{rows}x{n} rows of this workload's A in fp64, 2 warm-up + {iters} timed iterations")
     if rows != m:
         sample += f"; value = measured {its:.2f} it/s x {scale:.4f} (linear extrapolation to m = {m})"
-    return dict(value=its * scale, unit="it/s", cores=cpu_threads(), kind="port", sample=sample), parity
+    topo = cpu_topology()
+    return dict(value=its * scale, unit="it/s", cores=cpu_threads(), kind="port", sample=sample,
+                physical_cores=topo["physical"], logical_cpus=topo["logical"], blas=topo["blas"]), parity
 
 
-def run_workload(name, args, rank, world, device, steps, warmup, want_cpu, dist):
+def run_workload(name, args, rank, world, device, steps, warmup, want_cpu, dist, repeats=1):
+    import ctypes as C
     import fastoptsolver_amd as fos
-    from fastoptsolver_amd import distributed as fd
+    from fastoptsolver_amd import _lib, distributed as fd
     from fastoptsolver_amd.operators import vec_stats
     cfg = WORKLOADS[name]
     m, n = cfg["m"], cfg["n"]
@@ -156,10 +186,35 @@ def run_workload(name, args, rank, world, device, steps, warmup, want_cpu, dist)
         if float(flag.item()) < 1.0:
             comm = None
     args.comm_mode = ("c-abi/" + transport) if comm is not None else ("torch" if world > 1 else "none")
+    args.comm_info = None
+    if comm is not None:
+        # what the communicator itself reports (not what the launcher asked for) + the cost of the iteration's one
+        # collective alone: all-reduce of n + 1 floats, 100 back-to-back calls on the stream, max over ranks
+        nr, rk = C.c_int(), C.c_int()
+        _lib.check(comm.lib.fos_comm_info(comm.h, C.byref(nr), C.byref(rk)), "fos_comm_info")
+        probe = torch.zeros(cfg["n"] + 4, dtype=torch.float32, device=device)
+        for _ in range(10):
+            comm.allreduce(probe[: cfg["n"] + 1])
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(100):
+            comm.allreduce(probe[: cfg["n"] + 1])
+        e1.record()
+        e1.synchronize()
+        t_ar = torch.tensor([e0.elapsed_time(e1) * 10.0], dtype=torch.float64, device=device)      # us per call
+        dist.all_reduce(t_ar, op=dist.ReduceOp.MAX)
+        args.comm_info = dict(ranks_seen_by_communicator=int(nr.value), this_rank=int(rk.value), transport=comm.transport(),
+                              allreduce_elements=cfg["n"] + 1, allreduce_us_standalone=float(t_ar.item()))
+        comm.check()
     eng = fd.HipShardEngine(A, b, comm=comm, group=dist.group.WORLD if world > 1 else None)
     matvec_prob = fos.prepare(A, None)                       # same A, b = 0: power iteration / A^T b
     if comm is not None:
         matvec_prob.set_comm(comm)
+    if args.interleave != "auto":
+        eng.prob.replan(interleave=args.interleave == "on")
+        matvec_prob.replan(interleave=args.interleave == "on")
     if args.geometry:
         th, ch, rw, wg = (int(v) for v in args.geometry.split("x"))
         eng.prob.tune(th, ch, rw, wg)
@@ -199,41 +254,50 @@ def run_workload(name, args, rank, world, device, steps, warmup, want_cpu, dist)
         torch.cuda.synchronize()
 
     do_steps(warmup)
-    x_check, k_check, a1_chk = None, max(warmup, 3), a1
+    x_check, k_check, a1_chk, L_chk, x_moved = None, max(warmup, 10), a1, L, None
     if want_cpu and rank == 0 and world == 1:
         # Parity sample, outside the timed region: the same plan family on the rows the CPU baseline copies (all of
-        # cfg2; the first 65536 rows of cfg4 / cfg5), same L / alpha1 / alpha2, k_check iterations from x = 0.
-        # alpha1 keeps its meaning on the sample: the same fraction of the SAMPLE's ||A^T b||_inf (the full problem's
-        # alpha1 would threshold every coordinate of a 16x smaller problem to zero and make the check vacuous).
+        # cfg2; the first 65536 rows of cfg4 / cfg5), k_check >= 10 iterations from x = 0.  On a row sample alpha1 and L
+        # keep their MEANING: the same fraction of the sample's ||A^T b||_inf, and the sample's own power-iteration L
+        # (with the full problem's L the step would be 16x too short and the iterate would barely move).
         rows = min(m, SAMPLE_ROWS)
-        a1_chk = a1
         sub = eng if rows == m and warmup == k_check else fd.HipShardEngine(A[:rows], b[:rows])
         if sub is not eng:
             if rows != m:
                 atb_s = sub.prob.gemv_pair(torch.zeros(n, device=device), 0.0)
                 a1_chk = cfg["a1_frac"] * vec_stats(None, atb_s, None)[3]
-            sub.reset(tau=tau, alpha1=a1_chk, alpha2=a2)
+                L_chk = fos.prepare(A[:rows], None).power_iter(v0)[0]
+            if args.interleave != "auto":
+                sub.prob.replan(interleave=args.interleave == "on")
+            sub.reset(tau=1.0 / (L_chk + (a2 if a2 > 0 else 0.0)), alpha1=a1_chk, alpha2=a2)
             sub.st.run(k_check)
         x_check = sub.x().cpu().numpy()
-        assert np.linalg.norm(x_check) > 0.0, "parity sample did not move: vacuous check"
+        x_moved = float(np.linalg.norm(x_check))
+        assert x_moved > 0.0, "parity sample did not move: vacuous check"
         del sub
     # HIP events around the launches of the dominant kernel: all of them for short runs, every 8th otherwise (the
     # markers cost ~1 % when they bracket every launch of a long run)
     eng.prob.profile(1 if steps <= 32 else 8)
     eng.prob.profile_read()
-    fence()
-    t0 = time.perf_counter()
-    do_steps(steps)
-    fence()
-    elapsed = time.perf_counter() - t0
+    # `repeats` timed regions of EXACTLY `steps` iterations each, every one bracketed by barrier + synchronize on both sides
+    # and taken as the MAX over ranks; the reported time is their median ("median of 5 runs").
+    runs = []
+    for _ in range(repeats):
+        fence()
+        t0 = time.perf_counter()
+        do_steps(steps)
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        runs.append(el)
+    elapsed = float(np.median(runs))
     k_ms, k_launches = eng.prob.profile_read()
     eng.prob.profile(0)
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
     st = eng.status()
-    assert int(st.k) == warmup + steps and st.stopped == 0, (int(st.k), st.stopped)
+    assert int(st.k) == warmup + steps * repeats and st.stopped == 0, (int(st.k), st.stopped)
     assert math.isfinite(st.this_step) and st.this_step > 0.0, "iterate did not move: invalid run"
     replicas_identical = None
     if world > 1:
@@ -250,7 +314,8 @@ def run_workload(name, args, rank, world, device, steps, warmup, want_cpu, dist)
     b_iter = bytes_per_iter(hi - lo, n, cfg["dtype"])
     kern_us = k_ms * 1e3 / max(k_launches, 1)
     res = dict(
-        workload=name, ms_per_step=elapsed * 1e3 / steps, value=steps / elapsed, steps=steps, warmup=warmup,
+        workload=name, ms_per_step=elapsed * 1e3 / steps, value=steps / elapsed, steps=steps, warmup=warmup, repeats=repeats,
+        ms_per_step_runs=[e * 1e3 / steps for e in runs],
         kernel_us=kern_us, kernel_launches=int(k_launches), bytes_iter_per_gpu=b_iter,
         achieved_gbps=b_iter / (kern_us * 1e-6) / 1e9 if k_launches else None,
         step_gbps=b_iter / (elapsed / steps) / 1e9, lipschitz_s=lip_s, L=L, alpha1=a1, alpha2=a2,
@@ -258,10 +323,11 @@ def run_workload(name, args, rank, world, device, steps, warmup, want_cpu, dist)
         final_step_norm=st.this_step, replicas_identical=replicas_identical)
     cpu, parity = None, None
     if want_cpu and rank == 0 and world == 1:
-        cpu, parity = cpu_baseline(cfg, A, b, a1_chk, a2, L, x_check, k_check)
+        cpu, parity = cpu_baseline(cfg, A, b, a1_chk, a2, L_chk, x_check, k_check)
         assert parity is not None and parity < 1e-5, f"GPU iterate {k_check} differs from the oracle by {parity}: invalid run"
     res["cpu_baseline"], res["parity_rel_err"], res["parity_k"] = cpu, parity, k_check
     res["parity_rows"] = min(m, SAMPLE_ROWS)
+    res["parity_x_norm"] = x_moved
     del solver, eng, matvec_prob, A, b, comm
     torch.cuda.empty_cache()
     return res
@@ -293,6 +359,72 @@ def lbfgs_reference(device):
     return out
 
 
+def mfma_reference(device):
+    """north_star's "MFMA-busy counters": the two places this build uses the matrix cores - 16 Armijo candidates per pass
+    (fos_residual_batch) and 16 regularisation weights in lockstep (fos_fista_run_multi) - timed here with HIP events at
+    cfg2's shape, fp32 and bf16 storage; the SQ_VALU_MFMA_BUSY_CYCLES figures beside them are the committed rocprofv3 --pmc
+    passes of the same kernels (profiles/r01_linesearch_mfma.md, profiles/r02_multilambda.md), not counters of this run."""
+    import fastoptsolver_amd as fos
+    from fastoptsolver_amd import _core
+    cfg = WORKLOADS["cfg2"]
+    m, n = cfg["m"], cfg["n"]
+    A32, b = make_shard(cfg, 0, m, device)
+    pmc = {"f32": dict(line_search_mfma_util=0.322, path_mfma_util=(0.317, 0.344),
+                       instruction="v_mfma_f32_16x16x4_f32", source="profiles/r01_linesearch_mfma.md, profiles/r02_multilambda.md"),
+           "bf16": dict(line_search_mfma_util=0.115, path_mfma_util=(0.127, 0.124),
+                        instruction="v_mfma_f32_16x16x32_bf16 (candidates / residuals as three bf16 terms)",
+                        source="profiles/r01_linesearch_mfma.md, profiles/r02_multilambda.md")}
+    out = {}
+    for kind in ("f32", "bf16"):
+        A = A32 if kind == "f32" else A32.to(torch.bfloat16)
+        esz = 4 if kind == "f32" else 2
+        prob = fos.prepare(A, b)
+        leg = {}
+        # (1) 16 candidates per pass: ||A dlt_j||^2, j < 16, from one read of A
+        X = torch.randn(n, 16, device=device)
+        prob.residual_batch(X)
+        prob.profile(1)
+        prob.profile_read()
+        for _ in range(30):
+            prob.residual_batch(X)
+        ms, cnt = prob.profile_read()
+        prob.profile(0)
+        us = ms * 1e3 / max(cnt, 1)
+        terms = 3 if kind == "bf16" else 1
+        leg["line_search_16_candidates"] = dict(
+            kernel="residual_batch_mfma_kernel" if kind == "f32" else "residual_batch_mfma_bf16_kernel", kernel_us=us,
+            hbm_frac=m * n * esz / (us * 1e-6) / (HBM_PEAK_GBPS * 1e9), mfma_tflops=2.0 * m * n * 16 * terms / (us * 1e-6) / 1e12,
+            mfma_util_committed_pmc=pmc[kind]["line_search_mfma_util"])
+        # (2) 16 weights in lockstep: two GEMM-shaped products per iteration
+        lam = float((A32.T @ b).abs().max())
+        L = 4.0 * m
+        hs = []
+        for i in range(16):
+            st = _core.Fista(prob)
+            st.reset(1.0 / L, 0.2 * lam * 0.8 ** i, 0.0)
+            hs.append(st)
+        if _core.run_multi(hs, 3):
+            torch.cuda.synchronize()
+            best = 1e30
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _core.run_multi(hs, 40)
+                e1.record()
+                e1.synchronize()
+                best = min(best, e0.elapsed_time(e1) * 1e3 / 40)
+            leg["path_16_weights"] = dict(us_per_iteration=best, us_per_weight_iteration=best / 16,
+                                          a_reads_per_iteration=2, hbm_frac_on_two_reads=2.0 * m * n * esz / (best * 1e-6) / (HBM_PEAK_GBPS * 1e9),
+                                          mfma_util_committed_pmc=pmc[kind]["path_mfma_util"])
+        leg["instruction"], leg["pmc_source"] = pmc[kind]["instruction"], pmc[kind]["source"]
+        out[kind] = leg
+        del hs, prob
+    del A32, b
+    torch.cuda.empty_cache()
+    out["workload"] = f"cfg2 shape ({m}x{n}), 1 GPU; kernel_us by HIP events on the launch stream (fos_problem_profile)"
+    return out
+
+
 def load_traffic(workload):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass (profiles/)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -312,6 +444,8 @@ def roofline_obj(res, traffic_key):
         "unit": "GB/s",
         "frac": (res["achieved_gbps"] or 0.0) / HBM_PEAK_GBPS,
         "traffic": load_traffic(traffic_key) if traffic_key else None,   # PMC pass exists for the 1-GPU shapes only
+        "traffic_source": ("profiles/pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE per launch from a committed rocprofv3 "
+                           "--pmc pass of this workload, NOT a counter of this run") if traffic_key else None,
         "kernel": "fos::gemv_pair_kernel (single pass: r = A y - b and g += A^T r from the same registers)",
         "kernel_avg_us": res["kernel_us"],
         "kernel_launches_timed": res["kernel_launches"],
@@ -325,11 +459,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of exactly --steps iterations each; the median is reported (1 = a single region)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-target-ref", "--no-scale-ref", dest="no_target_ref", action="store_true",
                     help="skip the cfg2 (65536 x 8192) single-GPU measurement that the default N=1 run adds")
     ap.add_argument("--geometry", type=str, default="", help="THREADSxCHUNKSxROWSxWORKGROUPS override (tuning)")
+    ap.add_argument("--interleave", choices=("auto", "on", "off"), default="auto",
+                    help="row order of the streaming pass: planner default / round-robin rows / contiguous blocks (A/B)")
     ap.add_argument("--rows", type=int, default=0, help="override m (rehearsal / tuning only; reported in config)")
     args = ap.parse_args()
 
@@ -365,31 +503,58 @@ def main():
     name = args.workload or "cfg4"
     if args.rows:
         WORKLOADS[name] = dict(WORKLOADS[name], m=int(args.rows))
-    res = run_workload(name, args, rank, world, device, args.steps, args.warmup,
-                       want_cpu=not args.no_cpu_baseline, dist=dist)
+    default_run = world == 1 and name == "cfg4" and not args.no_target_ref and args.workload is None and not args.rows
+
+    def settle(seconds):
+        # Returning VRAM to the driver (empty_cache at the end of a workload) leaves the device busy for a while: the same
+        # allocation measured 306.6 us per cfg2 pass before and 316.8 us right after 64 GiB were freed, 306.6 us again after
+        # 5 s idle (profiles/r03_row_order.md, tools/order_probe.py).  Every workload of this run is therefore measured on
+        # a quiet device: small ones first, a pause after each free.
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        time.sleep(seconds)
+
+    # The riders of the default N=1 run go FIRST (2 GiB each), the 64 GiB headline last.
     target_ref = None
-    if world == 1 and name == "cfg4" and not args.no_target_ref and args.workload is None and not args.rows:
+    if default_run:
         try:
             r2 = run_workload("cfg2", args, rank, world, device, steps=200, warmup=10,
-                              want_cpu=not args.no_cpu_baseline, dist=dist)
+                              want_cpu=not args.no_cpu_baseline, dist=dist, repeats=args.repeats)
             c2 = WORKLOADS["cfg2"]
             target_ref = dict(
                 workload=f"cfg2: {c2['reg']} FISTA, A {c2['m']}x{c2['n']} f32 on 1 GPU - the configuration the "
                          ">=70 % single-GPU roofline target is quoted on",
                 value=r2["value"], unit="it/s", ms_per_step=r2["ms_per_step"], steps=r2["steps"], warmup=r2["warmup"],
+                repeats=r2["repeats"], ms_per_step_runs=r2["ms_per_step_runs"],
                 roofline=roofline_obj(r2, "cfg2"), cpu_baseline=r2["cpu_baseline"],
-                parity_rel_err_vs_cpu_at_warmup_iterate=r2["parity_rel_err"], kernel_plan=r2["plan"],
-                lipschitz_power_iteration_s=r2["lipschitz_s"])
+                parity_rel_err_vs_cpu_at_warmup_iterate=r2["parity_rel_err"],
+                parity={"rel_err": r2["parity_rel_err"], "iterate": r2["parity_k"], "rows": r2["parity_rows"],
+                        "x_norm": r2["parity_x_norm"]},
+                kernel_plan=r2["plan"], lipschitz_power_iteration_s=r2["lipschitz_s"])
         except Exception as exc:      # must not take the headline measurement down with it
             target_ref = dict(error=str(exc)[:200])
+        settle(2.0)
 
     # BASELINE config 3 (L-BFGS, ridge, on the cfg2 matrix) rides along in the default N=1 run as `lbfgs_ref`
     lbfgs_ref = None
-    if world == 1 and name == "cfg4" and not args.no_target_ref and args.workload is None and not args.rows:
+    if default_run:
         try:
             lbfgs_ref = lbfgs_reference(device)
         except Exception as exc:
             lbfgs_ref = dict(error=str(exc)[:200])
+        settle(3.0)
+
+    # BASELINE's MFMA evidence (16 Armijo candidates / 16 weights per pass on the matrix cores) as driver-timed numbers
+    mfma_ref = None
+    if default_run:
+        try:
+            mfma_ref = mfma_reference(device)
+        except Exception as exc:
+            mfma_ref = dict(error=str(exc)[:200])
+        settle(3.0)
+
+    res = run_workload(name, args, rank, world, device, args.steps, args.warmup,
+                       want_cpu=not args.no_cpu_baseline, dist=dist, repeats=args.repeats)
 
     if rank == 0:
         cfg = WORKLOADS[name]
@@ -401,6 +566,10 @@ def main():
             "steps": res["steps"],
             "warmup": res["warmup"],
             "ms_per_step": res["ms_per_step"],
+            "repeats": res["repeats"],
+            "ms_per_step_runs": res["ms_per_step_runs"],
+            "timing": "median over `repeats` timed regions of exactly `steps` iterations each (barrier + synchronize on both "
+                      "sides, max over ranks)",
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -420,16 +589,22 @@ def main():
                 "backend": backend if world > 1 else None,
                 "rehearsal": bool(args.rows) or (world > 1 and backend != "nccl"),
                 "replicas_identical": res["replicas_identical"],
+                "communicator": getattr(args, "comm_info", None),
             },
             "roofline": roofline_obj(res, name if world == 1 else None),
             "cpu_baseline": res["cpu_baseline"],
             "parity_rel_err_vs_cpu_at_warmup_iterate": res["parity_rel_err"],
             "parity": {"rel_err": res["parity_rel_err"], "iterate": res["parity_k"], "rows": res["parity_rows"],
+                       "x_norm": res["parity_x_norm"],
                        "what": "||x_gpu - x_oracle|| / ||x_oracle|| after `iterate` iterations from x = 0 on the first "
-                               "`rows` rows of this workload (same L, alpha1, alpha2); the run aborts above 1e-5"},
+                               "`rows` rows of this workload with the SAMPLE's own power-iteration L and its own alpha1 "
+                               "fraction (tau = 1/L_sample: the iterate moves as on a real problem); the run aborts above "
+                               "1e-5.  The full 2^20-row problem is checked at size by tests/test_gpu_parity.py::"
+                               "test_cfg4_full_size_properties"},
             "lipschitz_power_iteration_s": res["lipschitz_s"],
             "target_ref": target_ref,
             "lbfgs_ref": lbfgs_ref,
+            "mfma_ref": mfma_ref,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

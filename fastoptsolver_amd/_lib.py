@@ -10,7 +10,7 @@ FOS_F32, FOS_BF16 = 0, 1
 MODE_FISTA, MODE_DELTA, MODE_ISTA = 0, 1, 2
 PROX_L1, PROX_ENET = 0, 1
 STOP_NONE, STOP_STEP, STOP_RATIO, STOP_GRAD, STOP_LS_STALL = 0, 1, 2, 3, 4
-PLAN_NO_RESIDENT, PLAN_NO_TALL, PLAN_NO_WIDE, PLAN_NO_COLBLOCK, PLAN_CLUSTER = 1, 2, 4, 8, 16
+PLAN_NO_RESIDENT, PLAN_NO_TALL, PLAN_NO_WIDE, PLAN_NO_COLBLOCK, PLAN_CLUSTER, PLAN_INTERLEAVE, PLAN_NO_INTERLEAVE = 1, 2, 4, 8, 16, 32, 64
 
 
 class FistaParams(C.Structure):
@@ -61,6 +61,7 @@ SIGNATURES = {
     "fos_comm_mesh_connect": (_i32, [_vp, C.c_char_p]),
     "fos_comm_check": (_i32, [_vp, _vp]),
     "fos_comm_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "fos_comm_mesh_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(C.c_int64)]),
     "fos_comm_transport": (C.c_char_p, []),
     "fos_comm_allreduce": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "fos_problem_set_comm": (_i32, [_vp, _vp]),

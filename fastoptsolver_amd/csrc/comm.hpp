@@ -71,7 +71,9 @@ namespace fos {
 // Workgroup w owns a slice of the vector: push the slice to all peers, fence (system scope), publish the flags, wait for
 // the P flags of its own slice (bounded spin on the 100 MHz wall clock: a lost peer ends the kernel with an error flag
 // instead of hanging the GPU), sum.  Two inbox sets alternate: a rank can be at most one all-reduce ahead of the slowest.
-// All inbox / flag traffic uses system-scope atomics (sc0 sc1: no stale L2 lines on either side of the link).
+// Inboxes and flags are fine-grained allocations (coherent between devices while kernels run; round 2 had plain hipMalloc,
+// which two processes on ONE GPU cannot tell apart but which is no architectural guarantee across xGMI): data travels as
+// plain 16-byte stores behind a system-scope release fence, flags as system-scope release / acquire atomics.
 constexpr int MESH_MAXWG = 32;
 constexpr int MESH_MAXRANKS = 8;
 constexpr int MESH_THREADS = 256;
@@ -88,14 +90,25 @@ __global__ __launch_bounds__(MESH_THREADS) void mesh_allreduce_kernel(MeshPeers 
                                                                      int* __restrict__ err) {
   const int set = (int)(seq & 1ull);
   const int w = blockIdx.x, tid = threadIdx.x;
-  const long long per = (count + gridDim.x - 1) / gridDim.x;
-  const long long lo = (long long)w * per;
+  long long per = (count + gridDim.x - 1) / gridDim.x;
+  per = (per + 3) & ~3ll;                     // slices start on 16-byte boundaries (floats and doubles)
+  long long lo = (long long)w * per;
+  if (lo > count) lo = count;
   long long hi = lo + per;
   if (hi > count) hi = count;
-  // 1. push this slice into every rank's inbox row [set][rank]
+  // 1. push this slice into every rank's inbox row [set][rank].  The inboxes are FINE-GRAINED device memory
+  // (hipExtMallocWithFlags(hipDeviceMallocFinegrained): coherent across devices during a kernel), so plain 16-byte stores
+  // + a system-scope release fence before the flags are the architected way to hand the data over; slices start on
+  // 16-byte boundaries of the inbox row, the vector path needs the caller's buffer aligned likewise.
+  constexpr int VE = 16 / (int)sizeof(T);
+  const bool vec = (reinterpret_cast<uintptr_t>(buf) & 15u) == 0 && (lo % VE) == 0;
+  const long long nvec = vec ? (hi - lo) / VE : 0;
   for (int p = 0; p < nranks; ++p) {
     T* dst = reinterpret_cast<T*>(peers.inbox[p]) + ((long long)(set * nranks + rank)) * cap_elems;
-    for (long long i = lo + tid; i < hi; i += MESH_THREADS)
+    const uint4* s16 = reinterpret_cast<const uint4*>(buf + lo);
+    uint4* d16 = reinterpret_cast<uint4*>(dst + lo);
+    for (long long i = tid; i < nvec; i += MESH_THREADS) d16[i] = s16[i];
+    for (long long i = lo + nvec * VE + tid; i < hi; i += MESH_THREADS)
       __hip_atomic_store(dst + i, buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __threadfence_system();
@@ -121,9 +134,25 @@ __global__ __launch_bounds__(MESH_THREADS) void mesh_allreduce_kernel(MeshPeers 
     if (tid == 0) *err = 1;
     return;                                   // buf keeps this rank's partial: the host reports the failure
   }
-  // 4. sum the P inbox rows of this slice in rank order
+  // 4. sum the P inbox rows of this slice in rank order (every thread acquires at system scope behind the pollers)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   const T* rows = reinterpret_cast<const T*>(peers.inbox[rank]) + ((long long)set * nranks) * cap_elems;
-  for (long long i = lo + tid; i < hi; i += MESH_THREADS) {
+  for (long long i = tid; i < nvec; i += MESH_THREADS) {
+    T acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = (T)0;
+    for (int src = 0; src < nranks; ++src) {
+      const uint4 raw = reinterpret_cast<const uint4*>(rows + (long long)src * cap_elems + lo)[i];
+      T v[VE];
+      __builtin_memcpy(v, &raw, 16);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) acc[e] += v[e];
+    }
+    uint4 o;
+    __builtin_memcpy(&o, acc, 16);
+    reinterpret_cast<uint4*>(buf + lo)[i] = o;
+  }
+  for (long long i = lo + nvec * VE + tid; i < hi; i += MESH_THREADS) {
     T s = (T)0;
     for (int src = 0; src < nranks; ++src)
       s += __hip_atomic_load(rows + (long long)src * cap_elems + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -142,6 +171,7 @@ struct fos_comm {
   char* inbox = nullptr;                      // local [2][nranks][cap_bytes]
   unsigned long long* flags = nullptr;        // local [2][nranks][MESH_MAXWG]
   int* err = nullptr;                         // device flag raised by a timed-out wait
+  bool fine_grained = false;                  // inbox / flags came from hipExtMallocWithFlags(hipDeviceMallocFinegrained)
   size_t cap_bytes = 0;
   unsigned long long seq = 0;
   fos::MeshPeers peers{};

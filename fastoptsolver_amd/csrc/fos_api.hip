@@ -51,10 +51,11 @@ using fos::YSource;
 typedef void (*FusedLaunch)(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw,
                             float* slabs, double* rr_part, double* rr2_part, int nwg, hipStream_t st);
 
-template <typename T, int THREADS, int K, int R, int MINW, bool WITH_G, int NBUF, bool DUAL, bool DRAIN = false>
+template <typename T, int THREADS, int K, int R, int MINW, bool WITH_G, int NBUF, bool DUAL, bool DRAIN = false, bool CB = false,
+          bool IL = false>
 void fused_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, float* slabs,
                   double* rr_part, double* rr2_part, int nwg, hipStream_t st) {
-  hipLaunchKernelGGL((fos::gemv_pair_kernel<T, THREADS, K, R, true, MINW, WITH_G, NBUF, false, DUAL, DRAIN>), dim3(nwg),
+  hipLaunchKernelGGL((fos::gemv_pair_kernel<T, THREADS, K, R, true, MINW, WITH_G, NBUF, IL, DUAL, DRAIN, float, false, CB>), dim3(nwg),
                      dim3(THREADS), 0, st, reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part,
                      rr2_part);
 }
@@ -77,10 +78,10 @@ int raise_dynamic_lds(K kernel, size_t bytes, std::atomic<uint64_t>& done) {
   return FOS_OK;
 }
 
-template <typename T, int THREADS, int K, int R, int MINW, bool YLDS, int NB = 2>
+template <typename T, int THREADS, int K, int R, int MINW, bool YLDS, int NB = 2, bool IL = false>
 void fused_launch_dd(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, double* slabs,
                      double* rr_part, int nwg, hipStream_t st) {
-  auto kern = fos::gemv_pair_kernel<T, THREADS, K, R, true, MINW, true, NB, false, false, false, double, YLDS>;
+  auto kern = fos::gemv_pair_kernel<T, THREADS, K, R, true, MINW, true, NB, IL, false, false, double, YLDS>;
   constexpr size_t lds = YLDS ? (size_t)THREADS * K * fos::ElemTraits<T>::EPC * sizeof(double) : 0;
   if constexpr (lds > 65536) {
     static std::atomic<uint64_t> done{0};
@@ -94,26 +95,37 @@ struct MenuEntry {
   int dtype, threads, k, r;
   FusedLaunch with_g, resid_only, dual;   // dual may be null (geometry without a DUAL instantiation)
   FusedLaunchDD dd;                       // tall entries only: the same kernel writing fp64 slabs
+  // column-block instantiations (CB = true: negated-residual store + slab stride), only on the two geometries a column
+  // block can land on (block widths lie in (8192, 16384]); null elsewhere
+  FusedLaunch with_g_cb = nullptr, resid_only_cb = nullptr;
+  // interleaved-rows instantiations (IL = true: rows dealt round-robin, all CUs stream ONE contiguous window), on the
+  // geometries of rows >= 16 KiB; null elsewhere
+  FusedLaunch with_g_il = nullptr, resid_only_il = nullptr, dual_il = nullptr;
 };
 // Streaming geometries of the fp64-accumulating pass, ordered by capacity.  y and the gradient slice cost two VGPRs
 // per column here, so the wide rows take 512 threads x 8 chunks (2 waves per SIMD, 256 VGPRs) instead of 1024 x 4.
-struct DdEntry { int dtype, threads, k, r; FusedLaunchDD fn; };
+struct DdEntry { int dtype, threads, k, r; FusedLaunchDD fn; FusedLaunchDD fn_il = nullptr; };
 // three register tiles in flight where that measured faster (same-run ratio to the fp32 kernel, tools/bench_dd.py:
 // (512,4) fp32 0.96 -> 0.99, bf16 (256,4) 0.77 -> 0.83, bf16 (512,4) 0.77 -> 0.80; the 256-thread fp32 geometries lost
 // 2-3 % and the (512,8) fp32 geometry would spill: those keep two)
 #define DD_ENTRY(DT, T, TH, K, R, YL) { DT, TH, K, R, fused_launch_dd<T, TH, K, R, 2, YL, 2> }
 #define DD_ENTRY3(DT, T, TH, K, R, YL) { DT, TH, K, R, fused_launch_dd<T, TH, K, R, 2, YL, 3> }
+#define DD_ENTRY_IL(DT, T, TH, K, R, YL) { DT, TH, K, R, fused_launch_dd<T, TH, K, R, 2, YL, 2>, fused_launch_dd<T, TH, K, R, 2, YL, 2, true> }
+#define DD_ENTRY3_IL(DT, T, TH, K, R, YL) { DT, TH, K, R, fused_launch_dd<T, TH, K, R, 2, YL, 3>, fused_launch_dd<T, TH, K, R, 2, YL, 3, true> }
 const DdEntry kDdMenu[] = {
     DD_ENTRY(FOS_F32, float, 64, 1, 4, false), DD_ENTRY(FOS_F32, float, 64, 2, 2, false),
     DD_ENTRY(FOS_F32, float, 256, 1, 2, false), DD_ENTRY(FOS_F32, float, 256, 2, 2, false),
-    DD_ENTRY(FOS_F32, float, 256, 4, 1, false), DD_ENTRY3(FOS_F32, float, 512, 4, 1, false),
-    DD_ENTRY(FOS_F32, float, 512, 8, 1, true),
+    DD_ENTRY_IL(FOS_F32, float, 256, 4, 1, false), DD_ENTRY3_IL(FOS_F32, float, 512, 4, 1, false),
+    DD_ENTRY_IL(FOS_F32, float, 512, 8, 1, true),
     DD_ENTRY(FOS_BF16, fos::bf16_t, 64, 1, 2, false), DD_ENTRY(FOS_BF16, fos::bf16_t, 256, 1, 2, false),
-    DD_ENTRY(FOS_BF16, fos::bf16_t, 256, 2, 1, false), DD_ENTRY3(FOS_BF16, fos::bf16_t, 256, 4, 1, true),
-    DD_ENTRY3(FOS_BF16, fos::bf16_t, 512, 4, 1, true),
+    DD_ENTRY(FOS_BF16, fos::bf16_t, 256, 2, 1, false), DD_ENTRY3_IL(FOS_BF16, fos::bf16_t, 256, 4, 1, true),
+    // (blocks form: two tiles - with three the straight-line loop of round 3 needs 264 VGPRs and spills; interleaved: three)
+    { FOS_BF16, 512, 4, 1, fused_launch_dd<fos::bf16_t, 512, 4, 1, 2, true, 2>, fused_launch_dd<fos::bf16_t, 512, 4, 1, 2, true, 3, true> },
 };
 #undef DD_ENTRY
 #undef DD_ENTRY3
+#undef DD_ENTRY_IL
+#undef DD_ENTRY3_IL
 #define ENTRY(DT, T, TH, K, R, W) \
   { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, 2, false>, fused_launch<T, TH, K, R, W, false, 2, false>, nullptr }
 // NB register tiles in flight (profiles/r01_kbench_exp_*.log: 3 tiles are worth 1.5 % at n = 8192); D: with DUAL
@@ -125,7 +137,23 @@ const DdEntry kDdMenu[] = {
 // left for the second vector): TH2 x K2 must cover the same n.
 #define ENTRY_DRAIN(DT, T, TH, K, R, W, TH2, K2, W2) \
   { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, 2, false, true>, fused_launch<T, TH, K, R, W, false, 2, false, true>, \
-    fused_launch<T, TH2, K2, R, W2, true, 2, true, false> }
+    fused_launch<T, TH2, K2, R, W2, true, 2, true, false>, nullptr, \
+    fused_launch<T, TH, K, R, W, true, 2, false, true, true>, fused_launch<T, TH, K, R, W, false, 2, false, true, true>, \
+    fused_launch<T, TH, K, R, W, true, 2, false, true, false, true>, fused_launch<T, TH, K, R, W, false, 2, false, true, false, true>, \
+    fused_launch<T, TH2, K2, R, W2, true, 2, true, false, false, true> }
+// NB tiles + DUAL + the column-block forms
+#define ENTRY_NB_CB(DT, T, TH, K, R, W, NB) \
+  { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, NB, false>, fused_launch<T, TH, K, R, W, false, NB, false>, \
+    fused_launch<T, TH, K, R, W, true, 2, true>, nullptr, \
+    fused_launch<T, TH, K, R, W, true, NB, false, false, true>, fused_launch<T, TH, K, R, W, false, NB, false, false, true>, \
+    fused_launch<T, TH, K, R, W, true, NB, false, false, false, true>, fused_launch<T, TH, K, R, W, false, NB, false, false, false, true>, \
+    fused_launch<T, TH, K, R, W, true, 2, true, false, false, true> }
+// NB tiles + DUAL + the interleaved-rows forms
+#define ENTRY_NB_IL(DT, T, TH, K, R, W, NB) \
+  { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, NB, false>, fused_launch<T, TH, K, R, W, false, NB, false>, \
+    fused_launch<T, TH, K, R, W, true, 2, true>, nullptr, nullptr, nullptr, \
+    fused_launch<T, TH, K, R, W, true, NB, false, false, false, true>, fused_launch<T, TH, K, R, W, false, NB, false, false, false, true>, \
+    fused_launch<T, TH, K, R, W, true, 2, true, false, false, true> }
 #define ENTRY_D(DT, T, TH, K, R, W) \
   { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, 2, false>, fused_launch<T, TH, K, R, W, false, 2, false>, \
     fused_launch<T, TH, K, R, W, true, 2, true> }
@@ -136,11 +164,11 @@ const DdEntry kDdMenu[] = {
 const MenuEntry kMenu[] = {
     ENTRY_D(FOS_F32, float, 64, 1, 4, 2), ENTRY_D(FOS_F32, float, 64, 2, 4, 2),
     ENTRY_D(FOS_F32, float, 256, 1, 4, 2), ENTRY_D(FOS_F32, float, 256, 2, 4, 2), ENTRY_D(FOS_F32, float, 256, 4, 2, 2),
-    ENTRY_NB(FOS_F32, float, 512, 4, 1, 2, 3),   ENTRY_DRAIN(FOS_F32, float, 1024, 4, 1, 4, 512, 8, 2),
+    ENTRY_NB_IL(FOS_F32, float, 512, 4, 1, 2, 3),   ENTRY_DRAIN(FOS_F32, float, 1024, 4, 1, 4, 512, 8, 2),
     ENTRY_D(FOS_F32, float, 512, 8, 1, 2),  ENTRY(FOS_F32, float, 1024, 2, 2, 4),
     ENTRY(FOS_BF16, fos::bf16_t, 64, 1, 4, 2),                      // one wave per row: up to 512 bf16 columns
     ENTRY(FOS_BF16, fos::bf16_t, 256, 1, 4, 2), ENTRY(FOS_BF16, fos::bf16_t, 256, 2, 2, 2),
-    ENTRY_NB(FOS_BF16, fos::bf16_t, 256, 4, 1, 2, 3), ENTRY_NB(FOS_BF16, fos::bf16_t, 512, 4, 1, 2, 3),
+    ENTRY_NB_IL(FOS_BF16, fos::bf16_t, 256, 4, 1, 2, 3), ENTRY_NB_CB(FOS_BF16, fos::bf16_t, 512, 4, 1, 2, 3),
 };
 
 const MenuEntry* find_entry(int dtype, int threads, int k, int r) {
@@ -272,6 +300,7 @@ struct fos_problem {
   bool col_sharded = false;          // comm splits the COLUMNS instead: this rank holds A[:, its columns], x is partitioned
   unsigned plan_flags = 0;           // FOS_PLAN_* given to fos_problem_replan
   bool allow_resident = true;
+  bool il = false;                   // rows dealt round-robin to the workgroups (FOS_PLAN_INTERLEAVE / planner default for big rows)
   // plan
   int path = 0;                      // 0 fused, 1 two-pass fallback
   bool resident = false;             // small enough for the single-launch LDS-resident loop (resident.hpp)
@@ -501,6 +530,13 @@ __global__ __launch_bounds__(256) void sumsq_partials_kernel(const float* __rest
   if (threadIdx.x == 0) part[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
+// v *= scale, only once the solver has stopped (column-sharded runs: keeps the in-place all-reduce of a no-op iteration
+// from compounding; the values are not consumed any more, this only keeps them finite)
+__global__ __launch_bounds__(256) void unsum_if_stopped_kernel(float* __restrict__ v, int64_t m, float scale, const int* stopped) {
+  if (*stopped == 0) return;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) v[i] *= scale;
+}
+
 // Column blocks (rows wider than any single-pass kernel): phase 1 accumulates the negated residual block by block with the
 // residual-only form of the streaming kernel, phase 2 is the SAME with-gradient kernel per block with y = 0 and b = -r
 // (its row "dot" is then exactly r_i), writing its columns of full-width slabs.  A is read twice, at streaming speed.
@@ -519,11 +555,16 @@ int launch_pass_colblock(fos_problem* p, const YSource& ys, const float* b, bool
     yb.res_accum = cb > 0;
     // column-sharded: b enters the sum over the ranks once (rank 0)
     const float* b_here = (cb == 0 && !(p->col_sharded && p->comm->rank != 0)) ? b : nullptr;
-    p->entry->resid_only(Ab + c0 * esz, p->lda, b_here, p->m, nb, yb, p->rows_per_wg, p->slabs, p->rr2_part,
-                         p->rr2_part, p->nwg, p->stream);
+    p->entry->resid_only_cb(Ab + c0 * esz, p->lda, b_here, p->m, nb, yb, p->rows_per_wg, p->slabs, p->rr2_part,
+                            p->rr2_part, p->nwg, p->stream);
     LAUNCH_CHECK();
   }
   if (p->col_sharded) {              // r = sum over the column blocks of ALL ranks: the one m-vector exchange
+    if (ys.stopped != nullptr) {     // after a stop the passes above were no-ops and rneg still holds the last SUM: divide
+      hipLaunchKernelGGL(unsum_if_stopped_kernel, dim3(grid_1d(p->m, 256, 1024)), dim3(256), 0, p->stream, p->rneg, p->m,   // it back
+                         1.0f / (float)p->comm->nranks, ys.stopped);
+      LAUNCH_CHECK();
+    }
     int rc = reduce_across(p, p->rneg, (size_t)p->m, false);
     if (rc) return rc;
   }
@@ -538,8 +579,8 @@ int launch_pass_colblock(fos_problem* p, const YSource& ys, const float* b, bool
     const int nb = (int)std::min<int64_t>(W, p->n - c0);
     YSource yz{p->zeros, nullptr, nullptr, nullptr, ys.stopped};
     yz.slab_stride = p->n;
-    p->entry->with_g(Ab + c0 * esz, p->lda, p->rneg, p->m, nb, yz, p->rows_per_wg, p->slabs + c0, cb == 0 ? p->rr_part : p->rr2_part,
-                     p->rr2_part, p->nwg, p->stream);
+    p->entry->with_g_cb(Ab + c0 * esz, p->lda, p->rneg, p->m, nb, yz, p->rows_per_wg, p->slabs + c0, cb == 0 ? p->rr_part : p->rr2_part,
+                        p->rr2_part, p->nwg, p->stream);
     LAUNCH_CHECK();
   }
   *n_rr = p->nwg;
@@ -550,6 +591,10 @@ int launch_pass_inner(fos_problem* p, const YSource& ys, const float* b, bool wi
   if (p->path == 0 && p->colblock) return launch_pass_colblock(p, ys, b, with_g, n_rr);
   if (p->path == 0) {
     FusedLaunch fn = dual ? p->entry->dual : (with_g ? p->entry->with_g : p->entry->resid_only);
+    if (p->il) {
+      FusedLaunch fi = dual ? p->entry->dual_il : (with_g ? p->entry->with_g_il : p->entry->resid_only_il);
+      if (fi) fn = fi;
+    }
     fn(p->A, p->lda, b, p->m, (int)p->n, ys, p->rows_per_wg, p->slabs, p->rr_part, p->rr2_part, p->nwg, p->stream);
     LAUNCH_CHECK();
     *n_rr = p->nwg;
@@ -615,8 +660,15 @@ __global__ void rr_from_gbuf_kernel(const float* __restrict__ gbuf, int n, doubl
 int launch_slab_reduce_local(fos_problem* p, int n_rr, float* gbuf, double* rr_out, const int* stopped);
 // slabs -> gbuf[0..n], summed over the ranks when the problem is sharded; rr_out (nullable) = the global ||r||^2
 int launch_slab_reduce(fos_problem* p, int n_rr, float* gbuf, double* rr_out, const int* stopped) {
-  int rc = launch_slab_reduce_local(p, n_rr, gbuf, rr_out, stopped);
-  if (rc || !p->comm || p->col_sharded) return rc;      // column-sharded: the gradient block is local, ||r||^2 already global
+  if (!p->comm || p->col_sharded)                       // column-sharded: the gradient block is local, ||r||^2 already global
+    return launch_slab_reduce_local(p, n_rr, gbuf, rr_out, stopped);
+  // Row-sharded: gbuf is all-reduced IN PLACE, and the collective cannot be skipped on the device.  After a device-side
+  // stop the A pass is a no-op and the slabs keep the last active iteration's partials, so the local sum is re-derived
+  // from them UNCONDITIONALLY: every further enqueued iteration then all-reduces the same partials to the same sums (a
+  // guarded no-op would leave the previous SUM in gbuf and the next all-reduce would multiply it by the number of ranks:
+  // fp32 overflow after ~43 no-op iterations at 8 ranks).  rr_out is written after the exchange, guarded.
+  int rc = launch_slab_reduce_local(p, n_rr, gbuf, nullptr, nullptr);
+  if (rc) return rc;
   if ((rc = reduce_across(p, gbuf, (size_t)p->n + 1, false))) return rc;
   if (rr_out != nullptr) {
     hipLaunchKernelGGL(rr_from_gbuf_kernel, dim3(1), dim3(1), 0, p->stream, gbuf, (int)p->n, rr_out, stopped);
@@ -743,6 +795,19 @@ int aligned_vec(fos_problem* p, const float* v, const float** out) {
   return FOS_OK;
 }
 
+// Row order of the streaming pass.  Contiguous blocks per workgroup keep 256 streams 8-256 MiB apart; dealing the rows
+// round-robin (IL) makes all CUs read ONE contiguous window (256 rows = 16 MiB at 64 KiB rows) that sweeps the matrix.
+// profiles/r03_row_order.md (tools/skew_bench, tools/order_probe.py, in-bench A/B): on a quiet device the two are within
+// 2 % of each other either way (8 GiB: blocks 1186 us / IL 1208 us; 16 GiB: 2425-2458 / 2394-2417; 32 GiB: 4800-4840 /
+// 4777-4823; 64 GiB: 9546 / 9525), but for seconds after ANY large free on the device (this process's or the previous
+// one's - the driver releases and clears VRAM in the background) the block form loses 3-6 % while the interleaved form
+// does not move: cfg4 in bench.py, three fresh processes each: blocks 9989-9996 us, interleaved 9550-9571 us.  From 12 GiB
+// on the interleaved form is never behind, so it is the default there; below, blocks keep their quiet-state edge.
+bool il_default(const fos_problem* p) {
+  const int64_t bytes = p->m * p->n * (p->dtype == FOS_F32 ? 4 : 2);
+  return bytes >= (12ll << 30);
+}
+
 // Choose the kernel family for this problem; `flags` (FOS_PLAN_*) switch individual families off (fos_problem_replan).
 void apply_plan(fos_problem* p, unsigned flags) {
   const int64_t m = p->m, n = p->n;
@@ -752,6 +817,7 @@ void apply_plan(fos_problem* p, unsigned flags) {
   p->slab_stride = 0;
   p->vec4 = (n % 4 == 0);
   p->allow_resident = !(flags & FOS_PLAN_NO_RESIDENT);
+  p->il = (flags & FOS_PLAN_INTERLEAVE) ? true : (flags & FOS_PLAN_NO_INTERLEAVE) ? false : il_default(p);
   p->resident = fos::resident_fits(m, n) && p->allow_resident && p->comm == nullptr;
   const int epc = epc_of(p->dtype);
   const bool vec_ok = (n % epc == 0) && (p->lda % epc == 0) && ((reinterpret_cast<uintptr_t>(p->A) & 15u) == 0);
@@ -765,8 +831,11 @@ void apply_plan(fos_problem* p, unsigned flags) {
     const int64_t cap = 16384;
     const int64_t blocks = (n + cap - 1) / cap;
     p->cb_width = ((n + blocks - 1) / blocks + 63) / 64 * 64;
-    plan_fused(p, default_entry(p->dtype, p->cb_width), 0);
-    p->colblock = true;
+    const MenuEntry* ce = default_entry(p->dtype, p->cb_width);
+    if (ce && ce->with_g_cb && ce->resid_only_cb) {
+      plan_fused(p, ce, 0);
+      p->colblock = true;
+    } else plan_fallback(p);
   } else plan_fallback(p);
 }
 
@@ -934,8 +1003,18 @@ int fos_comm_mesh_create(fos_comm** out, int nranks, int rank, int64_t cap_bytes
   c->cap_bytes = ((size_t)cap_bytes + 63) & ~(size_t)63;
   const size_t inbox_bytes = 2 * (size_t)nranks * c->cap_bytes;
   const size_t flag_bytes = 2 * (size_t)nranks * fos::MESH_MAXWG * sizeof(unsigned long long);
-  hipError_t e = hipMalloc(&c->inbox, inbox_bytes);
-  if (e == hipSuccess) e = hipMalloc(&c->flags, flag_bytes);
+  // fine-grained (inter-device coherent) memory for everything a PEER reads or writes while kernels run; a runtime that
+  // refuses the flag for IPC-shared memory falls back to plain device memory (reported by fos_comm_mesh_info)
+  hipError_t e = hipExtMallocWithFlags((void**)&c->inbox, inbox_bytes, hipDeviceMallocFinegrained);
+  if (e == hipSuccess) e = hipExtMallocWithFlags((void**)&c->flags, flag_bytes, hipDeviceMallocFinegrained);
+  c->fine_grained = (e == hipSuccess);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (c->inbox) (void)hipFree(c->inbox);
+    c->inbox = nullptr; c->flags = nullptr;
+    e = hipMalloc(&c->inbox, inbox_bytes);
+    if (e == hipSuccess) e = hipMalloc(&c->flags, flag_bytes);
+  }
   if (e == hipSuccess) e = hipMalloc(&c->err, sizeof(int));
   if (e == hipSuccess) e = hipMemset(c->inbox, 0, inbox_bytes);
   if (e == hipSuccess) e = hipMemset(c->flags, 0, flag_bytes);
@@ -982,6 +1061,13 @@ int fos_comm_check(fos_comm* c, void* stream) {
   HIP_TRY(hipMemcpyAsync(&bad, c->err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   if (bad) return fail(FOS_ERR_STATE, "mesh all-reduce: a peer did not deliver within the time limit; results are invalid");
+  return FOS_OK;
+}
+
+int fos_comm_mesh_info(const fos_comm* c, int* fine_grained, int64_t* cap_bytes) {
+  if (!c || c->kind != 1) return fail(FOS_ERR_ARG, "fos_comm_mesh_info: not a mesh communicator");
+  if (fine_grained) *fine_grained = c->fine_grained ? 1 : 0;
+  if (cap_bytes) *cap_bytes = (int64_t)c->cap_bytes;
   return FOS_OK;
 }
 
@@ -1053,7 +1139,8 @@ int fos_problem_set_stream(fos_problem* p, void* stream) {
 int fos_problem_replan(fos_problem* p, unsigned flags) {
   if (!p) return fail(FOS_ERR_ARG, "fos_problem_replan: null");
   if (p->col_sharded) return fail(FOS_ERR_UNSUPPORTED, "fos_problem_replan: a column-sharded problem keeps its two-phase plan");
-  if (flags & ~(unsigned)(FOS_PLAN_NO_RESIDENT | FOS_PLAN_NO_TALL | FOS_PLAN_NO_WIDE | FOS_PLAN_NO_COLBLOCK | FOS_PLAN_CLUSTER))
+  if (flags & ~(unsigned)(FOS_PLAN_NO_RESIDENT | FOS_PLAN_NO_TALL | FOS_PLAN_NO_WIDE | FOS_PLAN_NO_COLBLOCK | FOS_PLAN_CLUSTER |
+                           FOS_PLAN_INTERLEAVE | FOS_PLAN_NO_INTERLEAVE))
     return fail(FOS_ERR_ARG, "fos_problem_replan: unknown flag");
   // the multi-lambda workspace follows its own plan (one-read cluster form or two products): rebuilt on first use
   {
@@ -1115,7 +1202,8 @@ int fos_problem_plan(const fos_problem* p, int32_t plan[8]) {
   plan[3] = p->entry ? p->entry->r : 0;
   plan[4] = p->nwg;
   plan[5] = p->nslabs;
-  plan[6] = (p->path == 0 ? 1 : 0) | (p->resident ? 2 : 0) | (p->tall ? 4 : 0) | (p->colblock ? 8 : 0) | (p->cp_cs ? 16 : 0);
+  plan[6] = (p->path == 0 ? 1 : 0) | (p->resident ? 2 : 0) | (p->tall ? 4 : 0) | (p->colblock ? 8 : 0) | (p->cp_cs ? 16 : 0) |
+            ((p->il && p->entry && p->entry->with_g_il && p->path == 0 && !p->colblock && !p->tall) ? 32 : 0);
   plan[7] = p->ncu;
   return FOS_OK;
 }
@@ -1195,7 +1283,7 @@ static int launch_pass_dd(fos_problem* p, const YSource& ys, double alpha2, cons
     nslabs = n_rr = p->nwg;
     stride = p->slab_stride;
   } else if (p->dd_entry) {
-    p->dd_entry->fn(p->A, p->lda, p->b, p->m, (int)p->n, ys, p->dd_rows_per_wg, p->slabs_dd, p->rr_dd, p->dd_nwg, p->stream);
+    (p->il && p->dd_entry->fn_il ? p->dd_entry->fn_il : p->dd_entry->fn)(p->A, p->lda, p->b, p->m, (int)p->n, ys, p->dd_rows_per_wg, p->slabs_dd, p->rr_dd, p->dd_nwg, p->stream);
     nslabs = n_rr = p->dd_nwg;
   } else {
     dim3 grid((unsigned)((p->n + 255) / 256), (unsigned)p->dd_two_pass_chunks);
@@ -1220,9 +1308,9 @@ static int launch_pass_dd(fos_problem* p, const YSource& ys, double alpha2, cons
   const double a2_here = (p->comm && p->comm->rank != 0) ? 0.0 : alpha2;
   hipLaunchKernelGGL(fos::slab_reduce_dd_kernel, dim3((unsigned)((p->n + fos::SRD_COLS - 1) / fos::SRD_COLS)),
                      dim3(fos::SRD_THREADS), 0, p->stream, p->slabs_dd,
-                     nslabs, (int)p->n, stride, p->rr_dd, n_rr, a2_here, l2vec, out, ys.stopped);
+                     nslabs, (int)p->n, stride, p->rr_dd, n_rr, a2_here, l2vec, out, p->comm ? nullptr : ys.stopped);
   LAUNCH_CHECK();
-  return reduce_across(p, out, (size_t)p->n + 1, true);
+  return reduce_across(p, out, (size_t)p->n + 1, true);      // (sharded: re-derived after a stop, see launch_slab_reduce)
 }
 
 int fos_gemv_pair_dd(fos_problem* p, const double* x, double alpha2, double* grad_rr) {
@@ -1498,7 +1586,7 @@ static int launch_finalize(fos_fista* f, int n_rr, double* hist_row = nullptr) {
   if (p->col_sharded) {
     // x is partitioned over the ranks: step norms, ||grad||^2, ||x||_1, ||x||^2 are sums over ALL column blocks
     if (!f->folded) HIP_TRY(hipMalloc(&f->folded, 8 * sizeof(double)));
-    hipLaunchKernelGGL(fold4_kernel, dim3(1), dim3(64), 0, p->stream, p->part, f->nupd, f->folded, &f->scal->stopped);
+    hipLaunchKernelGGL(fold4_kernel, dim3(1), dim3(64), 0, p->stream, p->part, f->nupd, f->folded, (const int*)nullptr);   // re-derived after a stop: the in-place all-reduce below must never see its own result
     LAUNCH_CHECK();
     int rc = reduce_across(p, f->folded, 4, true);
     if (rc) return rc;

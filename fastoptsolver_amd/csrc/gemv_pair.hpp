@@ -44,7 +44,8 @@ struct YSource {
   const int* stopped;    // device flag: non-zero -> kernel is a no-op (solver already stopped)
   double beta_val;
   const double* yd;      // explicit y in fp64 (L-BFGS iterate); used when y == nullptr and x_cur == nullptr
-  // Column-blocked passes over rows too wide for one workgroup's registers (fos_api.hip "column blocks"):
+  // Column-blocked passes over rows too wide for one workgroup's registers (fos_api.hip "column blocks"); read by the
+  // CB = true instantiations of gemv_pair_kernel only:
   float* res_out;        // nullable: the NEGATED residual of every row, res_out[i] = (res_accum ? res_out[i] : 0) - s_i
   int res_accum;
   int64_t slab_stride;   // floats between consecutive slab rows (0 = n): a block writes its columns of full-width slabs
@@ -162,8 +163,13 @@ __device__ inline double wave_sum(double v) { return wave_sum_dpp(v); }   // fp6
 // YLDS = true (ACC = double only) keeps y in LDS instead (THREADS*K*EPC doubles of dynamic shared memory, up to 128 KiB
 // of the CU's 160 KiB): the geometries for 64 KiB rows would otherwise need y + gradient slice = 256 KiB of the CU's
 // 512 KiB register file plus two row tiles, and spill.  LDS read traffic is 8 bytes per element of A, ~26 B/clk/CU.
+// CB = true is the column-block instantiation (rows wider than any geometry, fos_api.hip "column blocks"): it also
+// stores / accumulates the negated residual of every row (YSource::res_out) and honours YSource::slab_stride.  Those are
+// COMPILE-TIME so that the streaming instantiations' steady-state loop carries no exec-masked store block between the
+// post-barrier LDS reads and the next tile's loads (round 2 had them as runtime fields: +52 ISA lines, +10 branches in
+// the cfg2 loop, and the in-loop headline was 4.5 % slower; tests/test_hot_loop_isa.py guards the loop now).
 template <typename T, int THREADS, int K, int R, bool NT, int MINW, bool WITH_G = true, int NBUF = 2, bool IL = false,
-          bool DUAL = false, bool DRAIN = false, typename ACC = float, bool YLDS = false>
+          bool DUAL = false, bool DRAIN = false, typename ACC = float, bool YLDS = false, bool CB = false, bool SKEW = false>
 __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
     const T* __restrict__ A, int64_t lda, const float* __restrict__ b, int64_t m, int n, YSource ys,
     int64_t rows_per_wg, ACC* __restrict__ slabs, double* __restrict__ rr_part, double* __restrict__ rr2_part) {
@@ -234,6 +240,17 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
   const int64_t group = (int64_t)R * (IL ? gridDim.x : 1);   // rows between consecutive steps of this workgroup
   const int64_t first = IL ? (int64_t)blockIdx.x * R : 0;
   const int64_t nsteps = nrows > first ? (nrows - first + group - 1) / group : 0;
+  // SKEW: workgroup w walks its block starting w/gridDim of the way through it (and wraps): the workgroups' blocks start
+  // a power-of-two number of bytes apart, so without it all CUs sit at the same offset of their block at the same time
+  // - the same DRAM banks of every channel, different pages.
+  const int64_t skew = SKEW && !IL ? (nsteps * (int64_t)blockIdx.x) / (int64_t)gridDim.x : 0;
+  auto rot = [&](int64_t step) -> int64_t {
+    if constexpr (!SKEW) return step;
+    int64_t t = step + skew;
+    if (t >= nsteps) t -= nsteps;
+    if (t >= nsteps) t = nsteps - 1;        // prefetches past the end (clamped re-reads)
+    return t;
+  };
   const char* base = reinterpret_cast<const char*>(A);   // threads with no live chunk at all read column 0
   const int64_t row_bytes = lda * (int64_t)sizeof(T);
   double rr = 0.0, rr2 = 0.0;
@@ -246,7 +263,7 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
   auto issue = [&](int buf, int64_t step) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      int64_t row = row_lo + first + step * group + r;
+      int64_t row = row_lo + first + rot(step) * group + r;
       if (row >= row_hi) row = row_hi - 1;          // clamp: loaded but weighted by zero below
       bval[buf][r] = b_src[b != nullptr ? row : 0];
       const char* rp = base + row * row_bytes;
@@ -297,7 +314,7 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
       ACC s = (ACC)0;
 #pragma unroll
       for (int w = 0; w < NW; ++w) s += red[pb][r][w];
-      const int64_t row = row_lo + first + step * group + r;
+      const int64_t row = row_lo + first + rot(step) * group + r;
       const ACC bi = b != nullptr ? (ACC)bval[buf][r] : (ACC)0;
       if (row < row_hi) {
         s -= bi;
@@ -306,8 +323,9 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
         s = (ACC)0;
       }
       res[r] = s;
-      if (ys.res_out != nullptr && tid == 0 && row < row_hi)
-        ys.res_out[row] = (ys.res_accum ? ys.res_out[row] : 0.f) - (float)s;
+      if constexpr (CB) {
+        if (tid == 0 && row < row_hi) ys.res_out[row] = (ys.res_accum ? ys.res_out[row] : 0.f) - (float)s;
+      }
       if constexpr (DUAL) {
         ACC s2 = (ACC)0;
 #pragma unroll
@@ -365,7 +383,7 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
   }
 
   // ---- epilogue: this workgroup's slab -------------------------------------------------------------
-  ACC* slab = slabs + (int64_t)blockIdx.x * (ys.slab_stride ? ys.slab_stride : (int64_t)n);
+  ACC* slab = slabs + (int64_t)blockIdx.x * (CB && ys.slab_stride ? ys.slab_stride : (int64_t)n);
 #pragma unroll
   for (int c = 0; c < K; ++c) {
     if (WITH_G && live[c]) {

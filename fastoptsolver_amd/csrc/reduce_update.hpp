@@ -465,7 +465,8 @@ __global__ __launch_bounds__(1024) void grad_norm_stop_kernel(GradSrc gsrc, int 
                                                              const double* __restrict__ x_prev,
                                                              FistaScalars* __restrict__ scal, FistaParams prm,
                                                              double* __restrict__ partial_out = nullptr) {
-  if (scal->stopped != 0) return;
+  // (with partial_out the partial is re-derived even after a stop: it is all-reduced in place behind this kernel)
+  if (scal->stopped != 0 && partial_out == nullptr) return;
   __shared__ double ws[16];
   const double beta = scal->beta;
   double acc = 0.0;

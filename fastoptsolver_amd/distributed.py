@@ -80,8 +80,12 @@ class Comm:
         return cls(_solo=True, transport=transport)
 
     def transport(self):
-        return "mesh: one-shot full-mesh kernel over IPC-mapped inboxes" if self.kind == "mesh" else \
-            self.lib.fos_comm_transport().decode()
+        if self.kind == "mesh":
+            fine, cap = C.c_int32(), C.c_int64()
+            _lib.check(self.lib.fos_comm_mesh_info(self.h, C.byref(fine), C.byref(cap)), "fos_comm_mesh_info")
+            return (f"mesh: one-shot full-mesh kernel over IPC-mapped {'fine-grained' if fine.value else 'COARSE-GRAINED'} "
+                    f"inboxes of {cap.value} bytes per source")
+        return self.lib.fos_comm_transport().decode()
 
     def check(self):
         """Raise if a mesh all-reduce timed out waiting for a peer (synchronises); no-op for RCCL."""

@@ -32,9 +32,12 @@ enum { FOS_PROX_L1 = 0, FOS_PROX_ENET = 1 };
 enum { FOS_STOP_NONE = 0, FOS_STOP_STEP = 1, FOS_STOP_RATIO = 2, FOS_STOP_GRAD = 3, FOS_STOP_LS_STALL = 4 };
 
 enum { FOS_PLAN_NO_RESIDENT = 1, FOS_PLAN_NO_TALL = 2, FOS_PLAN_NO_WIDE = 4, FOS_PLAN_NO_COLBLOCK = 8,
-       FOS_PLAN_CLUSTER = 16 };   /* fos_problem_replan; FOS_PLAN_CLUSTER OPTS IN to the one-read cluster form of the
+       FOS_PLAN_CLUSTER = 16,     /* fos_problem_replan; FOS_PLAN_CLUSTER OPTS IN to the one-read cluster form of the
                                      multi-weight matrix-core pass (csrc/cluster_pass.hpp: cooperative launch, fp32,
                                      2049..16384 columns; measured 6 % faster at 65536 x 8192, slower at 16384 columns) */
+       FOS_PLAN_INTERLEAVE = 32,  /* rows of the streaming pass dealt round-robin to the workgroups (all CUs read one
+                                     contiguous window) instead of one contiguous block per workgroup ...           */
+       FOS_PLAN_NO_INTERLEAVE = 64 /* ... or never; neither bit: the planner's default for the shape */ };
 
 typedef struct fos_problem fos_problem;   /* A, b, launch plan, workspace            */
 typedef struct fos_comm fos_comm;         /* communicator of a row-sharded problem   */
@@ -89,7 +92,8 @@ int fos_problem_set_stream(fos_problem* p, void* stream);
  *               LDS-resident loop that fos_fista_run / _run_history / fos_power_iter then use; bit 2: n <= 64, the
  *               single pass is the row-per-thread kernel, which has no alignment requirements; bit 3: rows wider than
  *               any single-pass kernel - column blocks through the streaming kernel in two phases, A read twice;
- *               bit 4: set once fos_fista_run_multi has planned the one-read cluster form of the matrix-core pass), CUs} */
+ *               bit 4: set once fos_fista_run_multi has planned the one-read cluster form of the matrix-core pass;
+ *               bit 5: the streaming pass deals its rows round-robin to the workgroups), CUs} */
 int fos_problem_plan(const fos_problem* p, int32_t plan[8]);
 /* Re-run the planner with kernel families switched off (FOS_PLAN_* bits): NO_RESIDENT keeps small problems off the
  * one-launch LDS-resident loop, NO_TALL keeps n <= 64 off the row-per-thread pass, NO_WIDE keeps 16384 < n <= 32768 off
@@ -110,10 +114,10 @@ int fos_problem_set_gbuf(fos_problem* p, float* gbuf);
  * iteration - is summed over the ranks on the handle's stream before anything consumes it: ONE all-reduce of n + 1
  * floats per FISTA iteration (n + 1 doubles per L-BFGS fg), alpha2*y added after the reduction.  x_k, x_{k-1} and the
  * momentum scalars are replicated; every rank computes the identical update from identical numbers.  fos_fista_run
- * stays enqueue-only.  All ranks must issue the same calls in the same order.  (After a device-side stop or a parked
- * search the remaining enqueued iterations are no-ops, but their in-place all-reduces still run on the stale gradient
- * buffer, scaling it by the number of ranks each time: the iterate state is untouched, the gradient buffer is not - take a
- * fresh fos_fista_grad before using it again, as the Python layer does when it resumes a parked search.)
+ * stays enqueue-only.  All ranks must issue the same calls in the same order.  After a device-side stop or a parked
+ * search the remaining enqueued iterations are no-ops on the iterate state; their all-reduces still run (a collective
+ * cannot be skipped by one rank), on partials that are RE-DERIVED from the unchanged workspace each time, so the
+ * gradient buffer keeps the last active iteration's sums (it never compounds).
  * Transport: RCCL over xGMI, resolved with dlopen at first use (fos_comm_transport() says which library), or the
  * one-shot full-mesh kernel below.
  *   fos_comm_unique_id   rank 0 creates the 128-byte id; the caller broadcasts it out of band (e.g. torch.distributed)
@@ -132,6 +136,8 @@ int fos_comm_mesh_connect(fos_comm* c, const char* all_handles);
 int fos_comm_check(fos_comm* c, void* stream);
 int fos_comm_destroy(fos_comm* c);
 int fos_comm_info(const fos_comm* c, int* nranks, int* rank);
+/* Mesh communicators: whether inbox / flags are fine-grained (inter-device coherent) allocations, and the inbox row size. */
+int fos_comm_mesh_info(const fos_comm* c, int* fine_grained, int64_t* cap_bytes);
 const char* fos_comm_transport(void);
 /* In-place sum over the ranks of `count` floats (is_f64 = 0) or doubles (1) on `stream`; enqueues only. */
 int fos_comm_allreduce(fos_comm* c, void* buf, int64_t count, int is_f64, void* stream);

@@ -90,6 +90,49 @@ def test_every_fused_geometry(fos, threads, chunks, rows):
     assert _data.rel(g, g_ref) < TOL, plan
 
 
+@pytest.mark.parametrize("m,n,kind", [(1237, 8192, "f32"), (300, 5000, "f32"), (2050, 16384, "f32"), (100, 12288, "f32"),
+                                      (900, 8192, "bf16"), (333, 16384, "bf16"), (5, 8192, "f32"), (257, 16384, "f32")])
+def test_interleaved_rows_equal_block_rows(fos, m, n, kind):
+    """FOS_PLAN_INTERLEAVE: rows dealt round-robin to the workgroups instead of one contiguous block each (fp32 pass,
+    residual-only pass, DUAL/history pass, fp64 `fg` pass) - same sums in another order: against the oracle at 1e-5 /
+    1e-12, against the block form at 1e-6, a whole FISTA run with history against the oracle, fewer rows than workgroups."""
+    from fastoptsolver_amd import _core, _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(m + n)
+    A = rng.standard_normal((m, n)).astype(np.float32)
+    At = torch.as_tensor(A).to(torch.bfloat16 if kind == "bf16" else torch.float32)
+    A64 = At.to(torch.float64).numpy()
+    b = rng.standard_normal(m).astype(np.float32)
+    y = rng.standard_normal(n).astype(np.float32)
+    prob = fos.prepare(At.cuda(), b)
+    g_blk = prob.gemv_pair(_dev(y), alpha2=0.2).cpu().numpy()
+    prob.replan(interleave=True)
+    plan = prob.plan()
+    assert plan["interleave"] == 1 and plan["path"] == 0, plan
+    rr = torch.zeros(1, dtype=torch.float64, device="cuda")
+    g_il = prob.gemv_pair(_dev(y), alpha2=0.2, rr_out=rr).cpu().numpy()
+    g_ref, rr_ref = orc.gram_gradient(A64, y.astype(np.float64), b.astype(np.float64), 0.2)
+    assert _data.rel(g_il, g_ref) < TOL, plan
+    assert _data.rel(g_il, g_blk) < 1e-6
+    assert float(rr.cpu()) == pytest.approx(rr_ref, rel=TOL)
+    assert prob.residual_objective(_dev(y))[0] == pytest.approx(rr_ref, rel=TOL)        # residual-only instantiation
+    x = rng.standard_normal(n) * (1.0 + 1e-9 * rng.standard_normal(n))
+    out = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
+    _lib.check(lib.fos_gemv_pair_dd(prob.h, _core.ptr(_dev(x, torch.float64)), 0.37, _core.ptr(out)))   # fp64 fg pass
+    gd_ref, rrd_ref = orc.gram_gradient(A64, x, b.astype(np.float64), 0.37)
+    assert _data.rel(out.cpu().numpy()[:n], gd_ref) < 1e-12
+    assert float(out[n].cpu()) == pytest.approx(rrd_ref, rel=1e-12)
+    # a whole run with history (DUAL pass) on the interleaved plan
+    a1 = 0.1 * float(np.max(np.abs(A64.T @ b)))
+    np.random.seed(3)
+    v0 = np.random.randn(n)
+    np.random.seed(3)
+    xg, hg = fos.fista(prob, None, "lasso", a1, 0.0, max_iter=12, return_history=True)
+    xr, hr = orc.fista(A64, b.astype(np.float64), "lasso", a1, 0.0, max_iter=12, return_history=True, v0=v0)
+    assert _data.rel(_np(xg), xr) < TOL
+    assert np.allclose([float(o) for o in hg["obj"]], hr["obj"], rtol=2e-5)
+
+
 def test_gemv_pair_bf16(fos):
     """bf16 A / fp32 accumulate: judged against the oracle run on the bf16-rounded A."""
     rng = np.random.default_rng(11)
@@ -543,7 +586,23 @@ def test_cfg3_full_size_lbfgs(fos):
 def test_shard_size_properties(fos, kind):
     """The per-GPU shard of BASELINE configs 4 / 5 (131072 x 16384, fp32 / bf16): the geometries the headline runs on
     (1024-thread drained pipeline; 512 x 4 bf16), checked at that size through size-independent properties."""
-    m, n = 131072, 16384
+    _size_properties(fos, 131072, 16384, kind, shards=4)
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("kind", ["f32", "bf16"])
+def test_cfg4_full_size_properties(fos, kind):
+    """BASELINE configs 4 / 5 at their FULL size on one GPU (2^20 x 16384: 64 GiB fp32 / 32 GiB bf16) - the workload
+    bench.py's headline times at N = 1: every row against an independent fp64 torch matmul, affine, the 8-shard
+    decomposition of the 8-GPU run, bit reproducibility, 10 solver iterations against fp64 torch."""
+    free, _total = torch.cuda.mem_get_info()
+    need = (2 ** 20) * 16384 * (4 if kind == "f32" else 2) + 8 * 2 ** 30
+    if free < need:
+        pytest.skip(f"needs {need / 2**30:.0f} GiB of free HBM, {free / 2**30:.0f} available")
+    _size_properties(fos, 2 ** 20, 16384, kind, shards=8)
+
+
+def _size_properties(fos, m, n, kind, shards):
     dt = torch.float32 if kind == "f32" else torch.bfloat16
     A, b = _bench_like_problem(m, n, dt, seed=1)
     g = torch.Generator(device="cuda").manual_seed(5)
@@ -571,15 +630,15 @@ def test_shard_size_properties(fos, kind):
     prob.gemv_pair(y1, rr_out=rr)
     assert float(rr) == pytest.approx(rr_ref, rel=TOL)
     # (3) row subsample against the oracle itself
-    rows = slice(70000, 70512)
+    rows = slice(m // 2 + 4464, m // 2 + 4976)
     sub = fos.prepare(A[rows], b[rows])
     g_ref, _ = orc.gram_gradient(A[rows].double().cpu().numpy(), y1.cpu().numpy().astype(np.float64),
                                  b[rows].cpu().numpy().astype(np.float64), 0.0)
     assert _data.rel(sub.gemv_pair(y1).cpu().numpy(), g_ref) < TOL
-    # (4) shard sum == whole (the decomposition the 8 ranks of configs 4 / 5 compute), fixed order
+    # (4) shard sum == whole (the decomposition the ranks of configs 4 / 5 compute), fixed order
     acc = torch.zeros(n, dtype=torch.float64, device="cuda")
-    for p in range(4):
-        sl = slice(p * m // 4, (p + 1) * m // 4)
+    for p in range(shards):
+        sl = slice(p * m // shards, (p + 1) * m // shards)
         acc += fos.prepare(A[sl], b[sl]).gemv_pair(y1).double()
     assert float((acc - full).norm() / full.norm()) < 2e-6
     # (5) bit reproducibility

@@ -252,6 +252,24 @@ def _mesh_worker(rank, world, port, out_dir):
     x, h = fos.fista(As, bs, "elasticnet", a1, a2, max_iter=40, L=L, return_history=True, backtracking=True,
                      t_init_factor=2.0, comm=comm)
     out["xbt"], out["objbt"] = np.asarray(x), np.asarray(h["obj"])
+    # (2b) a device-side stop inside ONE enqueue-only run of 300 iterations: ~295 no-op iterations whose all-reduces still
+    # run.  The gradient buffer must keep the last active iteration's sums (an in-place all-reduce of a stale SUM would
+    # double it per iteration: inf after 128) - compared with a run of exactly that many iterations.
+    eng2 = fd.HipShardEngine(As, bs, comm=comm)
+    eng2.reset(tau=1.0 / (L + a2), alpha1=a1, alpha2=a2)
+    eng2.run(5)
+    step5 = float(eng2.status().this_step)
+    eng2.reset(tau=1.0 / (L + a2), alpha1=a1, alpha2=a2, tol_step=1.0001 * step5)
+    eng2.run(300)
+    st2 = eng2.status()
+    out["stop_k"], out["stop_flag"] = np.asarray(int(st2.k)), np.asarray(int(st2.stopped))
+    out["gbuf_stopped"] = eng2.gbuf[: eng2.n + 1].cpu().numpy()
+    eng3 = fd.HipShardEngine(As, bs, comm=comm)
+    eng3.reset(tau=1.0 / (L + a2), alpha1=a1, alpha2=a2)
+    eng3.run(int(st2.k))
+    out["gbuf_exact"] = eng3.gbuf[: eng3.n + 1].cpu().numpy()
+    out["x_stopped"], out["x_exact"] = eng2.x().cpu().numpy(), eng3.x().cpu().numpy()
+    del eng2, eng3
     s = fos.LBFGSSolver("ridge", 0.0, a2).fit(As, bs, comm=comm)
     out["xl"], out["nfev"] = np.asarray(s.x_), np.asarray(s.nfev_)
     comm.check()
@@ -320,6 +338,9 @@ def test_one_shot_mesh_allreduce_two_processes(tmp_path):
     x_ref, h_ref = orc.fista(A, b, "elasticnet", a1, a2, max_iter=40, L=L, return_history=True, backtracking=True,
                              t_init_factor=2.0)
     assert _data.rel(r0["xbt"], x_ref) < TOL and np.allclose(r0["objbt"], h_ref["obj"], rtol=TOL)
+    assert int(r0["stop_flag"]) == 1 and 1 <= int(r0["stop_k"]) <= 6, (int(r0["stop_flag"]), int(r0["stop_k"]))   # FOS_STOP_STEP
+    assert np.isfinite(r0["gbuf_stopped"]).all() and np.array_equal(r0["gbuf_stopped"], r0["gbuf_exact"])
+    assert np.array_equal(r0["x_stopped"], r0["x_exact"])
     ref = orc.LBFGSSolver("ridge", 0.0, a2).fit(A, b)
     assert _data.rel(r0["xl"], ref.x_) < TOL and int(r0["nfev"]) == ref.nfev_
     lam = float(np.max(np.abs(A.T @ b)))
