@@ -108,6 +108,7 @@ SIGNATURES = {
     "fos_lbfgs_two_loop_dd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
     "fos_lbfgs_direction_work": (_i64, [_i64]),
     "fos_lbfgs_direction_dd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "fos_lbfgs_direction_cols": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i64]),
     "fos_vec_stats_dd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "fos_vec_axpby_dd": (_i32, [_f64, _vp, _f64, _vp, _vp, _i64, _vp]),
     "fos_linesearch_begin": (_f64, [C.POINTER(LineSearchState), _f64, _f64, _f64]),

@@ -78,10 +78,10 @@ int raise_dynamic_lds(K kernel, size_t bytes, std::atomic<uint64_t>& done) {
   return FOS_OK;
 }
 
-template <typename T, int THREADS, int K, int R, int MINW, bool YLDS, int NB = 2, bool IL = false>
+template <typename T, int THREADS, int K, int R, int MINW, bool YLDS, int NB = 2, bool IL = false, bool KEEPCVT = false>
 void fused_launch_dd(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, double* slabs,
                      double* rr_part, int nwg, hipStream_t st) {
-  auto kern = fos::gemv_pair_kernel<T, THREADS, K, R, true, MINW, true, NB, IL, false, false, double, YLDS>;
+  auto kern = fos::gemv_pair_kernel<T, THREADS, K, R, true, MINW, true, NB, IL, false, false, double, YLDS, false, false, KEEPCVT>;
   constexpr size_t lds = YLDS ? (size_t)THREADS * K * fos::ElemTraits<T>::EPC * sizeof(double) : 0;
   if constexpr (lds > 65536) {
     static std::atomic<uint64_t> done{0};
@@ -118,45 +118,45 @@ const DdEntry kDdMenu[] = {
     DD_ENTRY_IL(FOS_F32, float, 256, 4, 1, false), DD_ENTRY3_IL(FOS_F32, float, 512, 4, 1, false),
     DD_ENTRY_IL(FOS_F32, float, 512, 8, 1, true),
     DD_ENTRY(FOS_BF16, fos::bf16_t, 64, 1, 2, false), DD_ENTRY(FOS_BF16, fos::bf16_t, 256, 1, 2, false),
-    DD_ENTRY(FOS_BF16, fos::bf16_t, 256, 2, 1, false), DD_ENTRY3_IL(FOS_BF16, fos::bf16_t, 256, 4, 1, true),
-    // (blocks form: two tiles - with three the straight-line loop of round 3 needs 264 VGPRs and spills; interleaved: three)
-    { FOS_BF16, 512, 4, 1, fused_launch_dd<fos::bf16_t, 512, 4, 1, 2, true, 2>, fused_launch_dd<fos::bf16_t, 512, 4, 1, 2, true, 3, true> },
+    DD_ENTRY(FOS_BF16, fos::bf16_t, 256, 2, 1, false),
+    // bf16 rows of 4 chunks per thread: the pass is VALU-bound (56 VALU instructions per 16-byte chunk: unpack + convert
+    // for the dot, AGAIN for the gradient update, 16 v_fma_f64), so these keep the converted tile across the barrier
+    // (KEEPCVT: 40 instructions) and pay with registers - two tiles in flight instead of three, per-chunk scheduling
+    // barriers, the cross-wave sum through the DPP ladder.  tools/dd_bench: 262144 x 8192 69.5 -> 78.2 % of 8 TB/s,
+    // 131072 x 16384 66.6 -> 74.5 %.
+    { FOS_BF16, 256, 4, 1, fused_launch_dd<fos::bf16_t, 256, 4, 1, 2, true, 2, false, true>,
+      fused_launch_dd<fos::bf16_t, 256, 4, 1, 2, true, 2, true, true> },
+    { FOS_BF16, 512, 4, 1, fused_launch_dd<fos::bf16_t, 512, 4, 1, 2, true, 2, false, true>,
+      fused_launch_dd<fos::bf16_t, 512, 4, 1, 2, true, 2, true, true> },
 };
 #undef DD_ENTRY
 #undef DD_ENTRY3
 #undef DD_ENTRY_IL
 #undef DD_ENTRY3_IL
+// with-gradient / residual-only pair of a geometry: NB register tiles, drained or not, column-block (CB) or interleaved (IL)
+#define PAIR(T, TH, K, R, W, NB, DRAIN, CB, IL) \
+  fused_launch<T, TH, K, R, W, true, NB, false, DRAIN, CB, IL>, fused_launch<T, TH, K, R, W, false, NB, false, DRAIN, CB, IL>
+// Every entry carries the column-block pair: a COLUMN-SHARDED problem (fos_problem_set_comm_cols) runs the two-phase
+// plan at whatever width a rank's block has; the unsharded planner only ever lands on the two widest geometries.
 #define ENTRY(DT, T, TH, K, R, W) \
-  { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, 2, false>, fused_launch<T, TH, K, R, W, false, 2, false>, nullptr }
-// NB register tiles in flight (profiles/r01_kbench_exp_*.log: 3 tiles are worth 1.5 % at n = 8192); D: with DUAL
-#define ENTRY_NB(DT, T, TH, K, R, W, NB) \
-  { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, NB, false>, fused_launch<T, TH, K, R, W, false, NB, false>, \
-    fused_launch<T, TH, K, R, W, true, 2, true> }
+  { DT, TH, K, R, PAIR(T, TH, K, R, W, 2, false, false, false), nullptr, nullptr, PAIR(T, TH, K, R, W, 2, false, true, false) }
+// D: with DUAL
+#define ENTRY_D(DT, T, TH, K, R, W) \
+  { DT, TH, K, R, PAIR(T, TH, K, R, W, 2, false, false, false), fused_launch<T, TH, K, R, W, true, 2, true>, nullptr, \
+    PAIR(T, TH, K, R, W, 2, false, true, false) }
+// NB register tiles in flight (profiles/r01_kbench_exp_*.log: 3 tiles are worth 1.5 % at n = 8192) + DUAL + the
+// interleaved-rows forms (rows >= 16 KiB)
+#define ENTRY_NB_IL(DT, T, TH, K, R, W, NB) \
+  { DT, TH, K, R, PAIR(T, TH, K, R, W, NB, false, false, false), fused_launch<T, TH, K, R, W, true, 2, true>, nullptr, \
+    PAIR(T, TH, K, R, W, NB, false, true, false), PAIR(T, TH, K, R, W, NB, false, false, true), \
+    fused_launch<T, TH, K, R, W, true, 2, true, false, false, true> }
 // drained pipeline (profiles/r01_kbench_exp2_*: best form for 64 KiB rows), with DUAL
 // The DUAL pass of such an entry runs another geometry of the same row step R (the 1024-thread form has no registers
 // left for the second vector): TH2 x K2 must cover the same n.
 #define ENTRY_DRAIN(DT, T, TH, K, R, W, TH2, K2, W2) \
-  { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, 2, false, true>, fused_launch<T, TH, K, R, W, false, 2, false, true>, \
-    fused_launch<T, TH2, K2, R, W2, true, 2, true, false>, nullptr, \
-    fused_launch<T, TH, K, R, W, true, 2, false, true, true>, fused_launch<T, TH, K, R, W, false, 2, false, true, true>, \
-    fused_launch<T, TH, K, R, W, true, 2, false, true, false, true>, fused_launch<T, TH, K, R, W, false, 2, false, true, false, true>, \
+  { DT, TH, K, R, PAIR(T, TH, K, R, W, 2, true, false, false), fused_launch<T, TH2, K2, R, W2, true, 2, true, false>, nullptr, \
+    PAIR(T, TH, K, R, W, 2, true, true, false), PAIR(T, TH, K, R, W, 2, true, false, true), \
     fused_launch<T, TH2, K2, R, W2, true, 2, true, false, false, true> }
-// NB tiles + DUAL + the column-block forms
-#define ENTRY_NB_CB(DT, T, TH, K, R, W, NB) \
-  { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, NB, false>, fused_launch<T, TH, K, R, W, false, NB, false>, \
-    fused_launch<T, TH, K, R, W, true, 2, true>, nullptr, \
-    fused_launch<T, TH, K, R, W, true, NB, false, false, true>, fused_launch<T, TH, K, R, W, false, NB, false, false, true>, \
-    fused_launch<T, TH, K, R, W, true, NB, false, false, false, true>, fused_launch<T, TH, K, R, W, false, NB, false, false, false, true>, \
-    fused_launch<T, TH, K, R, W, true, 2, true, false, false, true> }
-// NB tiles + DUAL + the interleaved-rows forms
-#define ENTRY_NB_IL(DT, T, TH, K, R, W, NB) \
-  { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, NB, false>, fused_launch<T, TH, K, R, W, false, NB, false>, \
-    fused_launch<T, TH, K, R, W, true, 2, true>, nullptr, nullptr, nullptr, \
-    fused_launch<T, TH, K, R, W, true, NB, false, false, false, true>, fused_launch<T, TH, K, R, W, false, NB, false, false, false, true>, \
-    fused_launch<T, TH, K, R, W, true, 2, true, false, false, true> }
-#define ENTRY_D(DT, T, TH, K, R, W) \
-  { DT, TH, K, R, fused_launch<T, TH, K, R, W, true, 2, false>, fused_launch<T, TH, K, R, W, false, 2, false>, \
-    fused_launch<T, TH, K, R, W, true, 2, true> }
 // Ordered by capacity (threads*k*EPC columns); first entry that fits n is the default.
 // The 64-thread entries give narrow rows (65..512 columns) one WAVE per row instead of a 256-thread workgroup whose
 // lanes would mostly idle (200000 x 256 ran at 18 % of the roofline on the 256-thread geometry); they are launched
@@ -168,7 +168,7 @@ const MenuEntry kMenu[] = {
     ENTRY_D(FOS_F32, float, 512, 8, 1, 2),  ENTRY(FOS_F32, float, 1024, 2, 2, 4),
     ENTRY(FOS_BF16, fos::bf16_t, 64, 1, 4, 2),                      // one wave per row: up to 512 bf16 columns
     ENTRY(FOS_BF16, fos::bf16_t, 256, 1, 4, 2), ENTRY(FOS_BF16, fos::bf16_t, 256, 2, 2, 2),
-    ENTRY_NB_IL(FOS_BF16, fos::bf16_t, 256, 4, 1, 2, 3), ENTRY_NB_CB(FOS_BF16, fos::bf16_t, 512, 4, 1, 2, 3),
+    ENTRY_NB_IL(FOS_BF16, fos::bf16_t, 256, 4, 1, 2, 3), ENTRY_NB_IL(FOS_BF16, fos::bf16_t, 512, 4, 1, 2, 3),
 };
 
 const MenuEntry* find_entry(int dtype, int threads, int k, int r) {
@@ -198,14 +198,15 @@ const MenuEntry kWideF32 = {FOS_F32, fos::WD_THREADS, fos::WD_K, 1, wide_launch<
 template <typename T, int NC, int LOAD, bool WITH_G, bool DUAL>
 void tall_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, float* slabs,
                  double* rr_part, double* rr2_part, int nwg, hipStream_t st) {
-  hipLaunchKernelGGL((fos::gemv_tall_kernel<T, NC, LOAD, WITH_G, DUAL>), dim3(nwg), dim3(fos::TL_THREADS), 0, st,
-                     reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part, rr2_part);
+  // the staged float4 copy streams one contiguous span: non-temporal (8000000 x 5: 61 -> 70 % of 8 TB/s, tools/tall_bench)
+  hipLaunchKernelGGL((fos::gemv_tall_kernel<T, NC, LOAD, WITH_G, DUAL, float, LOAD == fos::TL_STAGE4>), dim3(nwg),
+                     dim3(fos::TL_THREADS), 0, st, reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part, rr2_part);
 }
 template <typename T, int NC, int LOAD>
 void tall_launch_dd(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, double* slabs,
                     double* rr_part, int nwg, hipStream_t st) {
-  hipLaunchKernelGGL((fos::gemv_tall_kernel<T, NC, LOAD, true, false, double>), dim3(nwg), dim3(fos::TL_THREADS), 0, st,
-                     reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part, (double*)nullptr);
+  hipLaunchKernelGGL((fos::gemv_tall_kernel<T, NC, LOAD, true, false, double, LOAD == fos::TL_STAGE4>), dim3(nwg),
+                     dim3(fos::TL_THREADS), 0, st, reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part, (double*)nullptr);
 }
 template <typename T, bool VEC>
 void tallq_launch_dd(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, double* slabs,
@@ -289,6 +290,22 @@ int grid_1d(int64_t n, int per_block, int cap) {
 
 }  // namespace
 
+// Device + pinned workspace of fos_lbfgs_minimize, cached on the problem handle: round 2 allocated it per fit (7 hipMalloc +
+// hipHostMalloc + 2 events per fg, and the hipFree's at the end drain the device) inside an 8 ms fit.
+struct LbfgsWork {
+  int64_t n = 0;
+  double *g = nullptr, *g_old = nullptr, *d = nullptr, *x_old = nullptr, *S = nullptr, *Y = nullptr, *vl = nullptr;
+  double* host = nullptr;              // pinned: 16 doubles
+  unsigned long long* t_start = nullptr;   // device: wall-clock stamp taken in front of an evaluation
+  double ticks_per_ms = 1e5;           // hipDeviceAttributeWallClockRate (kHz)
+  ~LbfgsWork() {
+    void* bufs[] = {g, g_old, d, x_old, S, Y, vl, t_start};
+    for (void* q : bufs)
+      if (q) (void)hipFree(q);
+    if (host) (void)hipHostFree(host);
+  }
+};
+
 struct fos_problem {
   const void* A = nullptr;
   const float* b = nullptr;
@@ -297,6 +314,7 @@ struct fos_problem {
   hipStream_t stream = nullptr;
   int ncu = 256;
   fos_comm* comm = nullptr;          // row-sharded problem: sums of partial results go through it (comm.hpp)
+  LbfgsWork* lbfgs = nullptr;        // fos_lbfgs_minimize workspace, allocated by the first fit
   bool col_sharded = false;          // comm splits the COLUMNS instead: this rank holds A[:, its columns], x is partitioned
   unsigned plan_flags = 0;           // FOS_PLAN_* given to fos_problem_replan
   bool allow_resident = true;
@@ -346,6 +364,7 @@ struct fos_problem {
   int64_t n_pad = 0;
   // multi-lambda pass on the matrix cores (gram_batch.hpp): residual panel and the 16 gradient slab sets
   float* rbuf16 = nullptr;           // panel_rows x 16 floats
+  float* rcols16 = nullptr;          // column-sharded candidate pass: m x 16 partial residuals (summed over the ranks)
   float* slabs16 = nullptr;          // splits x 16 x n floats
   int64_t panel_rows = 0;
   int gram_splits = 0;
@@ -753,10 +772,54 @@ int launch_batch_product(fos_problem* p, const void* A, const float* b, int64_t 
 }
 
 // q[j] = ||A Xp_j - use_b*b||^2 -> out16 (device); Xp already in p->xp.
+// q[j] = sum_i R[i][j]^2 of an m x 16 residual block (column-sharded candidate pass, after the sum over the ranks)
+__global__ __launch_bounds__(256) void colnorms16_partials_kernel(const float* __restrict__ R, int64_t m, double* __restrict__ part,
+                                                                 const int* stopped) {
+  if (stopped != nullptr && *stopped != 0) return;
+  __shared__ double ws[16][17];
+  const int j = threadIdx.x & 15, sub = threadIdx.x >> 4;          // 16 rows per trip, a 64-byte row of R per 16 lanes
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 16 + sub; i < m; i += (int64_t)gridDim.x * 16) {
+    const double v = (double)R[i * fos::BT_NV + j];
+    acc += v * v;
+  }
+  ws[sub][j] = acc;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    double t = 0.0;
+    for (int s = 0; s < 16; ++s) t += ws[s][threadIdx.x];
+    part[(int64_t)blockIdx.x * fos::BT_NV + threadIdx.x] = t;
+  }
+}
+__global__ __launch_bounds__(256) void unsum16_if_stopped_kernel(float* __restrict__ v, int64_t count, float scale, const int* stopped) {
+  if (*stopped == 0) return;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) v[i] *= scale;
+}
+
 int launch_residual_batch(fos_problem* p, int use_b, double* out16, const int* stopped = nullptr) {
   int rc = prof_mark(p, true);
   if (rc) return rc;
   int nwg = 0;
+  if (p->col_sharded) {
+    // Column-sharded: ||A dlt_j||^2 = ||sum_p A_p dlt_{j,p}||^2.  Every rank's product 1 keeps its partial residuals
+    // (m x 16 floats), ONE all-reduce sums the blocks of all 16 candidates (4 MiB at m = 65536), the column norms follow.
+    if (!p->rcols16) HIP_TRY(hipMalloc(&p->rcols16, (size_t)p->m * fos::BT_NV * sizeof(float)));
+    const float* b_here = p->comm->rank == 0 ? p->b : nullptr;
+    if ((rc = launch_batch_product(p, p->A, b_here, p->m, use_b, p->rcols16, &nwg, stopped))) return rc;
+    if ((rc = prof_mark(p, false))) return rc;
+    if (stopped != nullptr) {        // a no-op product leaves the last SUM in place: divide it back before the in-place all-reduce
+      hipLaunchKernelGGL(unsum16_if_stopped_kernel, dim3(grid_1d(p->m * fos::BT_NV, 256, 1024)), dim3(256), 0, p->stream,
+                         p->rcols16, p->m * fos::BT_NV, 1.0f / (float)p->comm->nranks, stopped);
+      LAUNCH_CHECK();
+    }
+    if ((rc = reduce_across(p, p->rcols16, (size_t)p->m * fos::BT_NV, false))) return rc;
+    const int g = grid_1d(p->m, 16 * 16, 3 * p->ncu);
+    hipLaunchKernelGGL(colnorms16_partials_kernel, dim3(g), dim3(256), 0, p->stream, p->rcols16, p->m, p->q_part, stopped);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->q_part, g, fos::BT_NV, out16);
+    LAUNCH_CHECK();
+    return FOS_OK;
+  }
   if ((rc = launch_batch_product(p, p->A, p->b, p->m, use_b, nullptr, &nwg, stopped))) return rc;
   if ((rc = prof_mark(p, false))) return rc;
   hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->q_part, (int)nwg, fos::BT_NV, out16);
@@ -782,7 +845,7 @@ MultiLaunch find_multi(int64_t n, int nv) {
   return nullptr;
 }
 
-bool batch_supported(const fos_problem* p) { return p->path == 0 && !p->tall && !p->col_sharded; }   // fp32: f32 MFMA; bf16: 3-term bf16 MFMA
+bool batch_supported(const fos_problem* p) { return p->path == 0 && !p->tall; }   // fp32: f32 MFMA; bf16: 3-term bf16 MFMA
 
 // A caller vector the fused prologue can read with 16-byte loads.
 int aligned_vec(fos_problem* p, const float* v, const float** out) {
@@ -852,13 +915,15 @@ int ensure_dd(fos_problem* p) {
     nslabs = p->nwg; stride = p->slab_stride; n_rr = p->nwg;
   } else {
     const DdEntry* e = nullptr;
-    if (p->path == 0)
+    if (p->path == 0 && !p->col_sharded)      // column-sharded: the two-pass form, r all-reduced between the passes
       for (const auto& c : kDdMenu)
         if (c.dtype == p->dtype && (int64_t)c.threads * c.k * epc_of(p->dtype) >= p->n) { e = &c; break; }
     if (e) {
       p->dd_entry = e;
-      // fp64 form: two workgroups per CU for every 256-thread geometry (they hold 2 waves per SIMD at most 256 VGPRs each)
-      int nwg = p->ncu * (e->threads >= 512 ? 1 : e->threads == 256 ? 2 : 1024 / e->threads);
+      // fp64 form: two workgroups per CU for the 256-thread geometries (they hold 2 waves per SIMD at most 256 VGPRs
+      // each); four for the one-chunk geometry (76 VGPRs; 1048576 x 1024: 723 -> 660 us = 81 % of 8 TB/s, tools/dd_bench;
+      // the two-chunk geometry is best at two: 524288 x 2048 87.5 % against 82 %)
+      int nwg = p->ncu * (e->threads >= 512 ? 1 : e->threads == 256 ? (e->k == 1 ? 4 : 2) : 1024 / e->threads);
       const int64_t row_bytes = p->n * (p->dtype == FOS_F32 ? 4 : 2);
       const int64_t min_rows = std::max<int64_t>(2 * (int64_t)e->r, (65536 + row_bytes - 1) / row_bytes);   // fp64 slabs
       if (p->m < (int64_t)nwg * min_rows) nwg = (int)std::max<int64_t>(1, p->m / min_rows);
@@ -1114,7 +1179,10 @@ int fos_problem_set_comm_cols(fos_problem* p, fos_comm* c) {
   p->tall = false; p->slab_stride = 0; p->vec4 = true; p->resident = false;
   const int64_t blocks = (p->n + 16383) / 16384;
   p->cb_width = ((p->n + blocks - 1) / blocks + 63) / 64 * 64;
-  plan_fused(p, default_entry(p->dtype, p->cb_width), 0);
+  const MenuEntry* ce = default_entry(p->dtype, p->cb_width);
+  if (!ce || !ce->with_g_cb || !ce->resid_only_cb)
+    return fail(FOS_ERR_UNSUPPORTED, "fos_problem_set_comm_cols: no column-block kernel for this block width");
+  plan_fused(p, ce, 0);
   p->colblock = true;
   p->comm = c;
   p->col_sharded = true;
@@ -1186,10 +1254,11 @@ int fos_problem_destroy(fos_problem* p) {
   if (!p) return FOS_OK;
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   void* bufs[] = {p->slabs, p->rr_part, p->rr2_part, p->rvec, p->gbuf_own, p->ybuf, p->dscal, p->part, p->xp, p->q_part, p->bt_out,
-                  p->slabs_dd, p->rr_dd, p->lhist, p->rbuf16, p->slabs16, p->rneg, p->zeros, p->cp_xchg, p->cp_flags,
+                  p->slabs_dd, p->rr_dd, p->lhist, p->rbuf16, p->rcols16, p->slabs16, p->rneg, p->zeros, p->cp_xchg, p->cp_flags,
                   p->cp_error};
   for (void* q : bufs)
     if (q) (void)hipFree(q);
+  delete p->lbfgs;
   delete p;
   return FOS_OK;
 }
@@ -1271,9 +1340,67 @@ int fos_gemv_pair_f64(fos_problem* p, const double* y, double alpha2, float* gra
 
 // The fp64-accumulating pass for any y source: out[0..n) = A^T (A y - b) + alpha2*l2vec (l2vec may be NULL when alpha2 = 0),
 // out[n] = ||A y - b||^2, summed over the ranks of a sharded problem.  Not for resident-planned problems (callers check).
+__global__ __launch_bounds__(256) void sumsq_f64_partials_kernel(const double* __restrict__ v, int64_t m, double* __restrict__ part,
+                                                                const int* stopped) {
+  if (stopped != nullptr && *stopped != 0) return;
+  __shared__ double ws[4];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) acc += v[i] * v[i];
+  acc = fos::wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+__global__ __launch_bounds__(256) void unsum_f64_if_stopped_kernel(double* __restrict__ v, int64_t m, double scale, const int* stopped) {
+  if (*stopped == 0) return;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) v[i] *= scale;
+}
+
+// Column-sharded form (fos_problem_set_comm_cols): this rank holds A[:, its columns] and its block of y.  Pass 1: the
+// partial residual A_p y_p (rank 0 also subtracts b) in fp64, ONE all-reduce of the m doubles, pass 2: g_p = A_p^T r for
+// the local block; alpha2*y_p is local.  out[0..n) is this rank's block of the gradient, out[n] the global ||r||^2.
+static int launch_pass_dd_cols(fos_problem* p, const YSource& ys, double alpha2, const double* l2vec, double* out) {
+  const float* b_here = p->comm->rank == 0 ? p->b : nullptr;
+  const dim3 grid((unsigned)((p->n + 255) / 256), (unsigned)p->dd_two_pass_chunks);
+  if (p->dtype == FOS_F32)
+    hipLaunchKernelGGL(fos::residual_rows_kernel<float>, dim3(p->dd_nwg), dim3(256), 0, p->stream, (const float*)p->A, p->lda,
+                       b_here, p->m, (int)p->n, ys, p->rvec, p->rr_dd);
+  else
+    hipLaunchKernelGGL(fos::residual_rows_kernel<fos::bf16_t>, dim3(p->dd_nwg), dim3(256), 0, p->stream,
+                       (const fos::bf16_t*)p->A, p->lda, b_here, p->m, (int)p->n, ys, p->rvec, p->rr_dd);
+  LAUNCH_CHECK();
+  if (ys.stopped != nullptr) {       // after a stop pass 1 was a no-op and rvec still holds the last SUM: divide it back
+    hipLaunchKernelGGL(unsum_f64_if_stopped_kernel, dim3(grid_1d(p->m, 256, 1024)), dim3(256), 0, p->stream, p->rvec, p->m,
+                       1.0 / (double)p->comm->nranks, ys.stopped);
+    LAUNCH_CHECK();
+  }
+  int rc = reduce_across(p, p->rvec, (size_t)p->m, true);
+  if (rc) return rc;
+  const int n_rr = std::min(p->dd_nwg, 256);
+  hipLaunchKernelGGL(sumsq_f64_partials_kernel, dim3(n_rr), dim3(256), 0, p->stream, p->rvec, p->m, p->rr_dd, ys.stopped);
+  LAUNCH_CHECK();
+  if (p->dtype == FOS_F32)
+    hipLaunchKernelGGL((fos::transpose_rows_kernel<float, double>), grid, dim3(256), 0, p->stream, (const float*)p->A, p->lda,
+                       p->m, (int)p->n, p->rvec, ys.stopped, p->dd_rows_per_wg, p->slabs_dd);
+  else
+    hipLaunchKernelGGL((fos::transpose_rows_kernel<fos::bf16_t, double>), grid, dim3(256), 0, p->stream,
+                       (const fos::bf16_t*)p->A, p->lda, p->m, (int)p->n, p->rvec, ys.stopped, p->dd_rows_per_wg, p->slabs_dd);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(fos::slab_reduce_dd_kernel, dim3((unsigned)((p->n + fos::SRD_COLS - 1) / fos::SRD_COLS)),
+                     dim3(fos::SRD_THREADS), 0, p->stream, p->slabs_dd, p->dd_two_pass_chunks, (int)p->n, (int64_t)p->n, p->rr_dd,
+                     n_rr, alpha2, l2vec, out, ys.stopped);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
 static int launch_pass_dd(fos_problem* p, const YSource& ys, double alpha2, const double* l2vec, double* out) {
-  if (p->col_sharded) return fail(FOS_ERR_UNSUPPORTED, "the fp64 pass has no column-sharded form");
   int rc = ensure_dd(p);
+  if (rc) return rc;
+  if (p->col_sharded) {
+    if ((rc = prof_mark(p, true))) return rc;
+    if ((rc = launch_pass_dd_cols(p, ys, alpha2, l2vec, out))) return rc;
+    return prof_mark(p, false);
+  }
   if (rc) return rc;
   int nslabs = 0, n_rr = 0;
   int64_t stride = p->n;
@@ -1871,7 +1998,7 @@ int fos_fista_run(fos_fista* f, int iters) {
 // Up to 16 state machines in lockstep on the matrix cores (gram_batch.hpp): per iteration and per row panel, product 1
 // (R = A_panel Y - b, from HBM) and product 2 (G += R^T A_panel, the panel again from the Infinity Cache), then one
 // update kernel per state machine, which leaves its y_{k+1} in the candidate block of the next product 1.
-static int run_multi_mfma(fos_fista* const* fs, int nv, int iters) {
+static int run_multi_mfma(fos_fista* const* fs, int nv, int iters, bool controlled = false) {
   fos_problem* p = fs[0]->p;
   int rc = ensure_batch_workspace(p);
   if (rc) return rc;
@@ -1912,7 +2039,23 @@ static int run_multi_mfma(fos_fista* const* fs, int nv, int iters) {
   // candidate block: zero everywhere (padding columns, unused slots), then y_k of every state machine
   const size_t per_entry = is_bf16 ? 3 * sizeof(unsigned short) : sizeof(float);
   HIP_TRY(hipMemsetAsync(p->xp, 0, (size_t)p->n_pad * fos::BT_NV * per_entry, p->stream));
-  for (int v = 0; v < nv; ++v) {
+  // Controlled run (adaptive restart / step or ratio tolerance on any weight): momentum and stops are decided on the
+  // device per state machine, every iteration; a stopped weight is a masked column of the block.
+  fos::MultiControl mc{};
+  if (controlled) {
+    for (int v = 0; v < nv; ++v) {
+      fos_fista* f = fs[v];
+      if ((rc = flush_pending(f))) return rc;
+      f->host_valid = false; f->y_valid = false; f->plain_count = 0;
+      mc.scal[v] = f->scal; mc.part[v] = f->part2; mc.x_cur[v] = f->x_cur; mc.x_prev[v] = f->x_prev;
+      mc.adaptive_restart[v] = f->prm.adaptive_restart; mc.restart_threshold[v] = f->prm.restart_threshold;
+      mc.tol_step[v] = f->prm.tol_step; mc.tol_ratio[v] = f->prm.tol_ratio;
+    }
+    hipLaunchKernelGGL(fos::form_y_multi_kernel, dim3(grid_1d(p->n, 256, 64), nv), dim3(256), 0, p->stream, mc, (int)p->n, p->xp,
+                       is_bf16 ? fos::YOUT_XQ : fos::YOUT_XP, 1);
+    LAUNCH_CHECK();
+  }
+  for (int v = 0; v < nv && !controlled; ++v) {
     fos_fista* f = fs[v];
     if ((rc = flush_pending(f))) return rc;
     bool stopped = false;
@@ -1961,7 +2104,22 @@ static int run_multi_mfma(fos_fista* const* fs, int nv, int iters) {
     if ((rc = prof_mark(p, false))) return rc;
     // row-sharded problem: the 16 partial gradients (all row splits) are summed over the ranks before the updates
     if ((rc = reduce_across(p, p->slabs16, (size_t)p->gram_splits * fos::BT_NV * p->n, false))) return rc;
-    if (same_family) {                           // one launch updates all state machines
+    if (controlled) {                            // update (device beta) -> bookkeeping of all weights -> their y_{k+1}
+      fos::MultiUpdate mu{};
+      for (int v = 0; v < nv; ++v) {
+        fos_fista* f = fs[v];
+        mu.x_cur[v] = f->x_cur; mu.x_prev[v] = f->x_prev; mu.scal[v] = f->scal; mu.part[v] = f->part2;
+        mu.alpha1[v] = f->prm.alpha1; mu.alpha2[v] = f->prm.alpha2; mu.tau[v] = f->prm.tau;
+      }
+      hipLaunchKernelGGL(fos::fista_update_multi_kernel, dim3(fs[0]->nupd, nv), dim3(256), 0, p->stream, p->slabs16,
+                         p->gram_splits, (int)p->n, mu, fs[0]->prm, p->xp, is_bf16 ? fos::YOUT_XQ : fos::YOUT_XP, 0);
+      LAUNCH_CHECK();
+      hipLaunchKernelGGL(fos::fista_finalize_multi_kernel, dim3(nv), dim3(64), 0, p->stream, mc, fs[0]->nupd, fs[0]->prm);
+      LAUNCH_CHECK();
+      hipLaunchKernelGGL(fos::form_y_multi_kernel, dim3(grid_1d(p->n, 256, 64), nv), dim3(256), 0, p->stream, mc, (int)p->n, p->xp,
+                         is_bf16 ? fos::YOUT_XQ : fos::YOUT_XP, 0);
+      LAUNCH_CHECK();
+    } else if (same_family) {                    // one launch updates all state machines
       fos::MultiUpdate mu{};
       for (int v = 0; v < nv; ++v) {
         fos_fista* f = fs[v];
@@ -1991,7 +2149,7 @@ static int run_multi_mfma(fos_fista* const* fs, int nv, int iters) {
       }
     }
   }
-  for (int v = 0; v < nv; ++v) {
+  for (int v = 0; v < nv && !controlled; ++v) {
     fos_fista* f = fs[v];
     f->pending = false;
     const long long last = f->h_k - 1;
@@ -2011,9 +2169,21 @@ int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters) {
     if (!fs[v] || fs[v]->p != fs[0]->p) return fail(FOS_ERR_ARG, "fos_fista_run_multi: handles must share one problem");
   if (nv == 1) return fos_fista_run(fs[0], iters);
   fos_problem* p = fs[0]->p;
-  bool all_plain = true;
-  for (int v = 0; v < nv; ++v) all_plain = all_plain && plain_run(fs[v]);
-  const bool streaming = p->path == 0 && !p->tall && !p->colblock && !p->resident && !p->col_sharded && all_plain;
+  bool all_plain = true, controllable = true, same_family = true;
+  for (int v = 0; v < nv; ++v) {
+    all_plain = all_plain && plain_run(fs[v]);
+    // what the lockstep bookkeeping decides on the device: adaptive restart, step and ratio tolerances (the gradient-norm
+    // rule sits BEFORE the update and backtracking needs its own candidates per weight: those run one by one)
+    controllable = controllable && fs[v]->prm.tol_grad == 0.0 && !fs[v]->precise && !fs[v]->prm.tau_from_state;
+    const fos::FistaParams &a = fs[0]->prm, &c = fs[v]->prm;
+    same_family = same_family && a.mode == c.mode && a.prox_kind == c.prox_kind && a.delta == c.delta;
+  }
+  const bool shape_ok = p->path == 0 && !p->tall && !p->colblock && !p->resident && !p->col_sharded;
+  if (!all_plain && controllable && same_family && shape_ok && p->entry != &kWideF32 && (nv >= 3 || p->comm)) {
+    if (iters == 0) return FOS_OK;
+    return run_multi_mfma(fs, nv, iters, true);
+  }
+  const bool streaming = shape_ok && all_plain;
   // (a sharded problem takes the matrix-core pass for any number of weights: its 16 gradients are one 16 x n all-reduce)
   MultiLaunch fn = (streaming && !p->comm && p->dtype == FOS_F32 && p->entry != &kWideF32) ? find_multi(p->n, nv) : nullptr;
   // the two-product pass costs about two single-vector passes per iteration whatever the number of weights: it pays
@@ -2217,6 +2387,10 @@ static int enqueue_trial_batch(fos_fista* f, double t, double eta, int nv, int t
                        (int)p->n_pad, f->x_cur, f->x_prev, f->scal, f->prm, t, eta, nv, p->xp, p->part, t_from_state);
   hipLaunchKernelGGL(fos::fold_partials_kernel, dim3(1), dim3(fos::FOLD_THREADS), 0, p->stream, p->part, grid, fos::BT_W, p->bt_out);
   LAUNCH_CHECK();
+  if (p->col_sharded) {              // grad.dlt_j, ||dlt_j||^2, the counts, ||grad||^2, ||y||^2 are sums over the column blocks
+    int rc = reduce_across(p, p->bt_out, fos::BT_W, true);
+    if (rc) return rc;
+  }
   return launch_residual_batch(p, 0, p->bt_out + 64, stopped);
 }
 
@@ -2430,6 +2604,31 @@ int fos_lbfgs_direction_dd(const double* g, const double* S, const double* Y, in
   return launch_direction(g, S, Y, hist, head, cap, n, d_out, gd_out, work, (hipStream_t)stream);
 }
 
+// Column-sharded problems (fos_problem_set_comm_cols): every basis vector is partitioned over the ranks, so the Gram matrix
+// of the basis is a sum over the column blocks - the partial Gram matrices (a fixed-size block of VL_MAXPARTS slots, unused
+// slots zero, so that ranks with blocks of different width agree on the count) are all-reduced between the two kernels;
+// the coefficient recursion is then replicated and every rank combines its own block of d.  g.d and d.d come out global.
+int fos_lbfgs_direction_cols(fos_problem* p, const double* g, const double* S, const double* Y, int hist, int head, int cap,
+                             double* d_out, double* gd_out, double* work, int64_t work_doubles) {
+  if (!p || !p->col_sharded || !g || !d_out || !work || hist < 0 || cap < hist || (hist > 0 && (!S || !Y)) || head < 0 ||
+      (cap > 0 && head >= cap) || work_doubles < (int64_t)fos::VL_MAXPARTS * fos::VL_PSTRIDE)
+    return fail(FOS_ERR_ARG, "fos_lbfgs_direction_cols: bad argument (needs a column-sharded problem and 64 x 256 doubles of work)");
+  if (hist > fos::VL_MAXH) return fail(FOS_ERR_UNSUPPORTED, "fos_lbfgs_direction_cols: at most 10 pairs");
+  const int64_t n = p->n;
+  const int parts = vl_parts(n);
+  HIP_TRY(hipMemsetAsync(work, 0, (size_t)fos::VL_MAXPARTS * fos::VL_PSTRIDE * sizeof(double), p->stream));
+  hipLaunchKernelGGL(fos::lbfgs_gram_kernel, dim3(parts), dim3(fos::VL_THREADS), 0, p->stream, g, S, Y, hist, head,
+                     std::max(cap, 1), n, work);
+  LAUNCH_CHECK();
+  int rc = reduce_across(p, work, (size_t)fos::VL_MAXPARTS * fos::VL_PSTRIDE, true);
+  if (rc) return rc;
+  const int grid = (int)((n + fos::VL_THREADS - 1) / fos::VL_THREADS);
+  hipLaunchKernelGGL(fos::lbfgs_combine_kernel, dim3(grid), dim3(fos::VL_THREADS), 0, p->stream, g, S, Y, hist, head,
+                     std::max(cap, 1), n, (const double*)work, (int)fos::VL_MAXPARTS, d_out, gd_out);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
 int fos_vec_stats_dd(const double* x, const double* g, const double* d, int64_t n, double* out5, void* stream) {
   if (!out5 || n <= 0) return fail(FOS_ERR_ARG, "fos_vec_stats_dd: bad argument");
   hipLaunchKernelGGL((fos::vec_stats_kernel<double, double>), dim3(1), dim3(fos::LB_THREADS), 0, (hipStream_t)stream, x, g,
@@ -2453,39 +2652,36 @@ double fos_linesearch_step(fos_linesearch* ls, double stp, double f, double d) {
   return ls ? fos_ls_step_impl(ls, stp, f, d) : stp;
 }
 
-namespace {
-// device + pinned workspace of one fos_lbfgs_minimize call, released on every exit path
-struct LbfgsWork {
-  double *g = nullptr, *g_old = nullptr, *d = nullptr, *x_old = nullptr, *S = nullptr, *Y = nullptr, *vl = nullptr;
-  double* host = nullptr;              // pinned: 8 doubles
-  std::vector<hipEvent_t> ev;
-  ~LbfgsWork() {
-    void* bufs[] = {g, g_old, d, x_old, S, Y, vl};
-    for (void* q : bufs)
-      if (q) (void)hipFree(q);
-    if (host) (void)hipHostFree(host);
-    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
-  }
-};
-}  // namespace
-
 int fos_lbfgs_minimize(fos_problem* p, double alpha2, int max_iter, double pgtol, double* x, double* hist,
                        double* iterates, float* fg_ms, int fg_cap, fos_lbfgs_result* res) {
   if (!p || !x || !res || max_iter < 0) return fail(FOS_ERR_ARG, "fos_lbfgs_minimize: bad argument");
+  if (p->col_sharded)
+    return fail(FOS_ERR_UNSUPPORTED, "fos_lbfgs_minimize: a column-sharded problem partitions the iterate - every scalar of "
+                                     "the iteration is a sum over the ranks; use the driver above the ABI (LBFGSSolver.fit(cols=))");
   constexpr int M = 10, MAXLS = 20;
   constexpr double FACTR = 1e7, EPS = 2.220446049250313e-16;
   const int64_t n = p->n;
   const size_t nb = (size_t)n * sizeof(double);
   hipStream_t st = p->stream;
-  LbfgsWork w;
-  HIP_TRY(hipMalloc(&w.g, nb + 8 * sizeof(double)));
-  HIP_TRY(hipMalloc(&w.g_old, nb + 8 * sizeof(double)));
-  HIP_TRY(hipMalloc(&w.d, nb));
-  HIP_TRY(hipMalloc(&w.x_old, nb));
-  HIP_TRY(hipMalloc(&w.S, nb * M));
-  HIP_TRY(hipMalloc(&w.Y, nb * M));
-  HIP_TRY(hipMalloc(&w.vl, (size_t)fos_lbfgs_direction_work(n) * sizeof(double)));
-  HIP_TRY(hipHostMalloc(&w.host, 16 * sizeof(double)));
+  if (p->lbfgs == nullptr || p->lbfgs->n != n) {
+    delete p->lbfgs;
+    p->lbfgs = new LbfgsWork();
+    LbfgsWork& nw = *p->lbfgs;
+    HIP_TRY(hipMalloc(&nw.g, nb + 8 * sizeof(double)));
+    HIP_TRY(hipMalloc(&nw.g_old, nb + 8 * sizeof(double)));
+    HIP_TRY(hipMalloc(&nw.d, nb));
+    HIP_TRY(hipMalloc(&nw.x_old, nb));
+    HIP_TRY(hipMalloc(&nw.S, nb * M));
+    HIP_TRY(hipMalloc(&nw.Y, nb * M));
+    HIP_TRY(hipMalloc(&nw.vl, (size_t)fos_lbfgs_direction_work(n) * sizeof(double)));
+    HIP_TRY(hipHostMalloc(&nw.host, 16 * sizeof(double)));
+    HIP_TRY(hipMalloc(&nw.t_start, sizeof(unsigned long long)));
+    int dev = 0, khz = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) nw.ticks_per_ms = (double)khz;
+    nw.n = n;                                  // complete: a partial allocation is rebuilt by the next call
+  }
+  LbfgsWork& w = *p->lbfgs;
   // The scalars of an evaluation cross to the host in pinned memory the kernels write themselves (no copy engine on the
   // round trip):  [0..4] x.x, g.d, d.d, max|g|, ||x||_1   [5] ||r||^2   [6] g.d and [7] d.d of the newest direction
   // [8] sequence number of the evaluation, stored last (system-scope release): the host polls it rather than waiting for
@@ -2512,25 +2708,24 @@ int fos_lbfgs_minimize(fos_problem* p, double alpha2, int max_iter, double pgtol
 
   // loss and gradient at xv (lbfgs.py:43-54) plus g.d for the line search: enqueue only ...
   auto enqueue_fg = [&](const double* xv, double* gv, const double* dv) -> int {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (fg_ms && nfev < fg_cap) {
-      HIP_TRY(hipEventCreate(&e0));
-      w.ev.push_back(e0);
-      HIP_TRY(hipEventCreate(&e1));
-      w.ev.push_back(e1);
-      HIP_TRY(hipEventRecord(e0, st));
+    // device time of the evaluation for the reference's grad_call_times metric: a wall-clock stamp in front of the pass,
+    // read back by the statistics kernel behind it (hipEvents cost a 6.5 us bubble each on this stream: kernel trace)
+    const bool timed = fg_ms != nullptr;
+    if (timed) {
+      hipLaunchKernelGGL(fos::stamp_kernel, dim3(1), dim3(1), 0, st, w.t_start);
+      LAUNCH_CHECK();
     }
     int rc = fos_gemv_pair_dd(p, xv, alpha2, gv);
     if (rc) return rc;
-    if (e1) HIP_TRY(hipEventRecord(e1, st));
     seq += 1;
     hipLaunchKernelGGL((fos::vec_stats_kernel<double, double>), dim3(1), dim3(fos::LB_THREADS), 0, st, xv, (const double*)gv,
-                       dv, n, host_dev, (const double*)(gv + n), flag_dev, seq);
+                       dv, n, host_dev, (const double*)(gv + n), flag_dev, seq, timed ? w.t_start : nullptr);
     LAUNCH_CHECK();
     return FOS_OK;
   };
   // ... and take its scalars once the stream has drained
   auto take_fg = [&](double* loss, double* gd, double* gmax) {
+    if (fg_ms && nfev < fg_cap) fg_ms[nfev] = (float)(w.host[9] / w.ticks_per_ms);
     nfev += 1;
     *loss = 0.5 * w.host[5] + 0.5 * alpha2 * w.host[0];
     *gd = w.host[1];
@@ -2543,14 +2738,6 @@ int fos_lbfgs_minimize(fos_problem* p, double alpha2, int max_iter, double pgtol
   };
   auto finish = [&](double f, double gmax, int nit, int task) -> int {
     res->f = f; res->gmax = gmax; res->nit = nit; res->nfev = nfev; res->task = task; res->reserved = 0;
-    if (fg_ms) {
-      HIP_TRY(hipStreamSynchronize(st));
-      for (size_t i = 0; i + 1 < w.ev.size(); i += 2) {
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, w.ev[i], w.ev[i + 1]));
-        fg_ms[i / 2] = ms;
-      }
-    }
     return FOS_OK;
   };
 
@@ -2585,7 +2772,6 @@ int fos_lbfgs_minimize(fos_problem* p, double alpha2, int max_iter, double pgtol
     hipLaunchKernelGGL(fos::lbfgs_first_trial_kernel, dim3(ax_grid), dim3(256), 0, st, x, (const double*)w.d, stp, w.x_old, n);
     LAUNCH_CHECK();
     std::swap(g, g_old);                        // g_old holds the gradient at x_old; g receives the trial gradients
-    const size_t ev_mark = w.ev.size();
     if ((rc = enqueue_fg(x, g, w.d))) return rc;
     if ((rc = wait_fg())) return rc;
     const double gd0 = w.host[6];
@@ -2593,7 +2779,6 @@ int fos_lbfgs_minimize(fos_problem* p, double alpha2, int max_iter, double pgtol
     if (gd0 >= 0.0) {                           // not a descent direction: drop the memory (L-BFGS-B info = -4);
       HIP_TRY(hipMemcpyAsync(x, w.x_old, nb, hipMemcpyDeviceToDevice, st));   // the speculative evaluation never happened
       std::swap(g, g_old);
-      while (w.ev.size() > ev_mark) { (void)hipEventDestroy(w.ev.back()); w.ev.pop_back(); }
       if (hist_n == 0) return finish(f, gmax, nit, 3);
       hist_n = 0; head = 0;
       continue;

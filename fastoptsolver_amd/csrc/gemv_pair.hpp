@@ -169,7 +169,7 @@ __device__ inline double wave_sum(double v) { return wave_sum_dpp(v); }   // fp6
 // post-barrier LDS reads and the next tile's loads (round 2 had them as runtime fields: +52 ISA lines, +10 branches in
 // the cfg2 loop, and the in-loop headline was 4.5 % slower; tests/test_hot_loop_isa.py guards the loop now).
 template <typename T, int THREADS, int K, int R, bool NT, int MINW, bool WITH_G = true, int NBUF = 2, bool IL = false,
-          bool DUAL = false, bool DRAIN = false, typename ACC = float, bool YLDS = false, bool CB = false, bool SKEW = false>
+          bool DUAL = false, bool DRAIN = false, typename ACC = float, bool YLDS = false, bool CB = false, bool SKEW = false, bool KEEPCVT = false>
 __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
     const T* __restrict__ A, int64_t lda, const float* __restrict__ b, int64_t m, int n, YSource ys,
     int64_t rows_per_wg, ACC* __restrict__ slabs, double* __restrict__ rr_part, double* __restrict__ rr2_part) {
@@ -298,6 +298,7 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
             acc3 = fma_acc(a[e + 1], xv[c][e + 1], acc3);
           }
         }
+        if constexpr (KEEPCVT) __builtin_amdgcn_sched_barrier(0);
       }
       part[r] = wave_sum(acc0 + acc1);
       if constexpr (DUAL) part[R + r] = wave_sum(acc2 + acc3);
@@ -312,8 +313,12 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       ACC s = (ACC)0;
+      if constexpr (KEEPCVT && NW >= 8) {      // one partial per lane + the DPP ladder: 2 VGPRs instead of 2*NW
+        s = wave_sum(lane < NW ? red[pb][r][lane] : (ACC)0);
+      } else {
 #pragma unroll
       for (int w = 0; w < NW; ++w) s += red[pb][r][w];
+      }
       const int64_t row = row_lo + first + rot(step) * group + r;
       const ACC bi = b != nullptr ? (ACC)bval[buf][r] : (ACC)0;
       if (row < row_hi) {
@@ -323,8 +328,9 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
         s = (ACC)0;
       }
       res[r] = s;
-      if constexpr (CB) {
-        if (tid == 0 && row < row_hi) ys.res_out[row] = (ys.res_accum ? ys.res_out[row] : 0.f) - (float)s;
+      if constexpr (CB) {       // phase 1 of a column-blocked pass stores the residual; phase 2 (res_out == nullptr) only reads it
+        if (ys.res_out != nullptr && tid == 0 && row < row_hi)
+          ys.res_out[row] = (ys.res_accum ? ys.res_out[row] : 0.f) - (float)s;
       }
       if constexpr (DUAL) {
         ACC s2 = (ACC)0;
@@ -339,9 +345,11 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
 #pragma unroll
         for (int c = 0; c < K; ++c) {
           float a[EPC];
-          if constexpr (sizeof(ACC) == 8) {
+          if constexpr (sizeof(ACC) == 8 && !KEEPCVT) {
             // fp64 form: hide the tile from value numbering, or the compiler keeps the v_cvt_f64_f32 results of the dot
-            // phase alive across the barrier for reuse here (2 VGPRs per element of the tile: spills at 64 KiB rows)
+            // phase alive across the barrier for reuse here (2 VGPRs per element of the tile: spills at 64 KiB rows).
+            // KEEPCVT = true does keep them (bf16 storage: the second unpack + conversion is 16 of the 56 VALU
+            // instructions per chunk of a pass that is VALU-bound, and the raw tile is dead once converted)
             u32x4 t = tile[buf][r][c];
             asm volatile("" : "+v"(t));
             Tr::unpack(t, a);

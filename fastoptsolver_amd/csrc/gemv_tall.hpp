@@ -32,7 +32,7 @@ __host__ __device__ inline int tall_slab_stride(int n) { return (n + 3) & ~3; }
 //   TL_STAGE4  TL_STAGE for fp32 with 16-byte aligned block starts (A aligned, rows per workgroup a multiple of 4): the
 //              copy moves float4s - 3 load instructions per thread and block instead of 10 at n = 5
 enum : int { TL_DIRECT = 0, TL_VEC = 1, TL_STAGE = 2, TL_STAGE4 = 3 };
-template <typename T, int NC, int LOAD, bool WITH_G, bool DUAL, typename ST = float>
+template <typename T, int NC, int LOAD, bool WITH_G, bool DUAL, typename ST = float, bool STAGE_NT = false>
 __global__ __launch_bounds__(TL_THREADS) void gemv_tall_kernel(const T* __restrict__ A, int64_t lda,
                                                               const float* __restrict__ b, int64_t m, int n, YSource ys,
                                                               int64_t rows_per_wg, ST* __restrict__ slabs,
@@ -82,7 +82,10 @@ __global__ __launch_bounds__(TL_THREADS) void gemv_tall_kernel(const T* __restri
           const int i = 4 * (u * TL_THREADS + tid);
           f32x4 v = {0.f, 0.f, 0.f, 0.f};
           if (i + 3 < count) {
-            v = *reinterpret_cast<const f32x4*>(srcf + i);
+            // (the staged copy reads one contiguous span, 1 KiB per wave instruction: unlike the row-wise 16-byte loads of
+            // TL_VEC it can stream past the caches)
+            if constexpr (STAGE_NT) v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(srcf + i));
+            else v = *reinterpret_cast<const f32x4*>(srcf + i);
           } else if (i < count) {                                        // the block's last, partial quad
             v.x = srcf[i];
             if (i + 1 < count) v.y = srcf[i + 1];

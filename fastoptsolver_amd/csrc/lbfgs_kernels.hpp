@@ -412,8 +412,12 @@ __global__ __launch_bounds__(LB_THREADS) void vec_stats_kernel(const XT* __restr
                                                                double* __restrict__ out5,
                                                                const double* __restrict__ extra = nullptr,
                                                                unsigned long long* flag = nullptr,
-                                                               unsigned long long seq = 0) {
+                                                               unsigned long long seq = 0,
+                                                               const unsigned long long* t_start = nullptr) {
   __shared__ double lds[5][16];
+  // t_start (fos_lbfgs_minimize): the constant-rate wall clock read by stamp_kernel in front of the evaluation; this
+  // kernel runs right behind it, so (now - *t_start) is the evaluation's device time - out5[9], no hipEvent on the stream
+  const unsigned long long t_now = t_start != nullptr ? wall_clock64() : 0ull;
   double xx = 0.0, gd = 0.0, dd = 0.0, gm = 0.0, x1 = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += LB_THREADS) {
     const double xv = x ? (double)x[i] : 0.0, gv = g ? (double)g[i] : 0.0, dv = d ? (double)d[i] : 0.0;
@@ -434,12 +438,15 @@ __global__ __launch_bounds__(LB_THREADS) void vec_stats_kernel(const XT* __restr
     for (int i = 0; i < 16; ++i) { a += lds[0][i]; b += lds[1][i]; c += lds[2][i]; e = fmax(e, lds[3][i]); f += lds[4][i]; }
     out5[0] = a; out5[1] = b; out5[2] = c; out5[3] = e; out5[4] = f;
     if (extra != nullptr) out5[5] = *extra;
+    if (t_start != nullptr) out5[9] = (double)(t_now - *t_start);
     if (flag != nullptr) {                  // out5 in pinned host memory: the host polls `flag` instead of draining the stream
       __threadfence_system();
       __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
+
+__global__ void stamp_kernel(unsigned long long* out) { *out = wall_clock64(); }
 
 // out3 = { ||x||^2, ||x||_1, 0 }
 __global__ __launch_bounds__(LB_THREADS) void vec_norms_kernel(const float* __restrict__ x, int64_t n,

@@ -361,21 +361,24 @@ struct MultiUpdate {
   double beta[BT_NV], beta_next[BT_NV];
   double alpha1[BT_NV], alpha2[BT_NV], tau[BT_NV];
 };
+// host_beta = 0 (controlled runs): beta comes from each state machine's device scalars and no y is written (beta_{k+1} is
+// decided by fista_finalize_multi_kernel behind this launch; form_y_multi_kernel then fills the block).
 __global__ __launch_bounds__(256) void fista_update_multi_kernel(const float* __restrict__ slabs, int nslabs, int n,
                                                                 MultiUpdate mu, FistaParams prm0, float* __restrict__ y_block,
-                                                                int y_mode) {
+                                                                int y_mode, int host_beta = 1) {
   const int v = blockIdx.y;
   FistaParams prm = prm0;                       // mode / prox kind / delta are common to the path; weights and steps are not
   prm.alpha1 = mu.alpha1[v]; prm.alpha2 = mu.alpha2[v]; prm.tau = mu.tau[v];
   fista_update_body<true, true>(slabs + (int64_t)v * n, nslabs, GradSrc{nullptr, nullptr}, n, mu.x_cur[v], mu.x_prev[v], mu.scal[v], prm,
-                                mu.part[v], 1, mu.beta[v], nullptr, y_block, mu.beta_next[v], (int64_t)BT_NV * n, y_mode, v);
+                                mu.part[v], host_beta, mu.beta[v], nullptr, host_beta ? y_block : nullptr, mu.beta_next[v],
+                                (int64_t)BT_NV * n, y_mode, v);
 }
 
 // One wave: fold the partials and advance the scalar state.  iterative_solvers.py:204-221, :235-242, :325-342.
-__global__ __launch_bounds__(64) void fista_finalize_kernel(const double* __restrict__ part, int nparts,
-                                                           const double* __restrict__ rr_part, int n_rr,
-                                                           FistaScalars* __restrict__ scal, FistaParams prm,
-                                                           double* __restrict__ hist_row = nullptr) {
+__device__ inline void fista_finalize_body(const double* __restrict__ part, int nparts,
+                                           const double* __restrict__ rr_part, int n_rr,
+                                           FistaScalars* __restrict__ scal, const FistaParams& prm,
+                                           double* __restrict__ hist_row) {
   if (scal->stopped != 0) return;
   // issue every load before the first use: the partials were written by other CUs (L2 / MALL latency each)
   double s[4] = {0.0, 0.0, 0.0, 0.0};
@@ -444,6 +447,55 @@ __global__ __launch_bounds__(64) void fista_finalize_kernel(const double* __rest
   if (prm.tol_step > 0.0 && step < prm.tol_step) stop = STOP_STEP;
   if (stop == STOP_NONE && prm.tol_ratio > 0.0 && ratio < prm.tol_ratio) stop = STOP_RATIO;
   scal->stopped = stop;
+}
+__global__ __launch_bounds__(64) void fista_finalize_kernel(const double* __restrict__ part, int nparts,
+                                                           const double* __restrict__ rr_part, int n_rr,
+                                                           FistaScalars* __restrict__ scal, FistaParams prm,
+                                                           double* __restrict__ hist_row = nullptr) {
+  fista_finalize_body(part, nparts, rr_part, n_rr, scal, prm, hist_row);
+}
+
+// Lockstep weights with data-dependent control (adaptive restart, step / ratio tolerances per weight): the scalar
+// bookkeeping of ALL state machines in one launch (blockIdx.x = state machine), then their y_{k+1} into the Y block of the
+// next matrix-core product.  A stopped state machine is a masked column: its update, bookkeeping and y are no-ops and its
+// column of the block keeps the last y (the products still carry it along; nothing reads its gradient).
+struct MultiControl {
+  FistaScalars* scal[BT_NV];
+  const double* part[BT_NV];
+  const double* x_cur[BT_NV];
+  const double* x_prev[BT_NV];
+  int adaptive_restart[BT_NV];
+  double restart_threshold[BT_NV], tol_step[BT_NV], tol_ratio[BT_NV];
+};
+__global__ __launch_bounds__(64) void fista_finalize_multi_kernel(MultiControl mc, int nparts, FistaParams prm0) {
+  const int v = blockIdx.x;
+  FistaParams prm = prm0;
+  prm.adaptive_restart = mc.adaptive_restart[v];
+  prm.restart_threshold = mc.restart_threshold[v];
+  prm.tol_step = mc.tol_step[v];
+  prm.tol_ratio = mc.tol_ratio[v];
+  fista_finalize_body(mc.part[v], nparts, nullptr, 0, mc.scal[v], prm, nullptr);
+}
+// force: also write the columns of stopped state machines (the block's first fill)
+__global__ __launch_bounds__(256) void form_y_multi_kernel(MultiControl mc, int n, float* __restrict__ y_block, int y_mode,
+                                                          int force) {
+  const int v = blockIdx.y;
+  if (!force && mc.scal[v]->stopped != 0) return;
+  const double beta = mc.scal[v]->beta;
+  for (int col = blockIdx.x * 256 + threadIdx.x; col < n; col += gridDim.x * 256) {
+    const float yn = (float)form_y(mc.x_cur[v][col], mc.x_prev[v][col], beta);
+    if (y_mode == YOUT_XP) {
+      y_block[xp_index(col, v)] = yn;
+    } else {
+      unsigned short* xq = reinterpret_cast<unsigned short*>(y_block);
+      const unsigned short hi = f32_to_bf16_rn(yn);
+      const float r1 = yn - bf16_to_f32(hi);
+      const unsigned short mid = f32_to_bf16_rn(r1);
+      xq[xq_index(col, v, 0)] = hi;
+      xq[xq_index(col, v, 1)] = mid;
+      xq[xq_index(col, v, 2)] = f32_to_bf16_rn(r1 - bf16_to_f32(mid));
+    }
+  }
 }
 
 // Fresh loop state (fos_fista_reset): t = 1, ratio = inf, everything else 0 - written by the device so that the reset

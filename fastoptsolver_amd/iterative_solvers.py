@@ -594,12 +594,10 @@ def fista(A, b, reg_type: str, alpha1: float, alpha2: float, backtracking: bool 
     torch.distributed group, any backend) does it between the kernels from Python.
     ``cols=(lo, hi, n_total)`` with ``comm=``: COLUMN sharding for very wide A - A is this rank's columns [lo, hi) of
     all rows, b the whole vector; x is partitioned (the result and the history are this rank's block), one all-reduce of
-    an m-vector per iteration; no backtracking in this form."""
+    an m-vector per iteration (backtracking: plus ONE all-reduce of the 16 candidates' m-vectors per search)."""
     reset_metrics()
     prob, reducer = _sharded_problem(A, b, dtype, comm, group, cols)
     like = prob.like
-    if cols is not None and backtracking:
-        raise NotImplementedError("backtracking has no column-sharded form (||A dlt||^2 needs an m-vector per candidate)")
     if L is not None:
         L_val = float(L)
     elif cols is not None:
@@ -634,8 +632,6 @@ def fista_delta(A, b, reg_type: str, alpha1: float, alpha2: float, delta: float,
     assert delta > 2, "In FISTA-Δ, delta must be > 2 for convergence (course requirement)"
     prob, reducer = _sharded_problem(A, b, dtype, comm, group, cols)
     like = prob.like
-    if cols is not None and backtracking:
-        raise NotImplementedError("backtracking has no column-sharded form (||A dlt||^2 needs an m-vector per candidate)")
     if L is not None:
         L_val = float(L)
     elif cols is not None:
@@ -658,7 +654,8 @@ def fista_delta(A, b, reg_type: str, alpha1: float, alpha2: float, delta: float,
 # Regularisation path (extension)
 # ---------------------------------------------------------------------
 def fista_path(A, b, alphas, t_init_factor: float = 1.0, max_iter: int = 500, *, delta=None, L=None, dtype=None,
-               comm=None):
+               comm=None, tol: float = 0.0, tol_ratio: float = 0.0, adaptive_restart: bool = False,
+               restart_threshold: float = 1.0, return_info: bool = False):
     """Solve the same (A, b) for several regularisation weights at once.
 
     ``alphas`` is a sequence of ``(alpha1, alpha2)`` pairs.  The result is the list of solutions that
@@ -667,7 +664,12 @@ def fista_path(A, b, alphas, t_init_factor: float = 1.0, max_iter: int = 500, *,
     share one read of A per iteration in the multi-vector form of the single-pass kernel (fp32, n <= 8192); five to
     sixteen run on the matrix cores as two GEMM-shaped products per iteration for all of them (fp32 and bf16 storage,
     any streaming shape: csrc/gram_batch.hpp).  Shapes without such a kernel simply run one by one.  L is estimated once (one power iteration, one draw from the global
-    NumPy stream) unless given."""
+    NumPy stream) unless given.
+    ``adaptive_restart`` / ``restart_threshold`` / ``tol_ratio`` (fista's arguments of the same names) keep the lockstep:
+    momentum restarts and the ratio stop are decided per weight on the device every iteration and a stopped weight
+    becomes a masked column of the block (three or more weights, matrix-core pass).  ``tol`` adds the reference's
+    gradient-norm rule, which sits before the update: those runs go one by one.  ``return_info=True`` also returns
+    ``[(iterations, stop_code), ...]`` per weight."""
     reset_metrics()
     if delta is not None:
         assert delta > 2, "In FISTA-Δ, delta must be > 2 for convergence (course requirement)"
@@ -678,7 +680,9 @@ def fista_path(A, b, alphas, t_init_factor: float = 1.0, max_iter: int = 500, *,
     handles = []
     for a1, a2 in alphas:
         st = _core.Fista(prob)
-        st.reset(t_init_factor / (L_val + (a2 if a2 > 0 else 0.0)), a1, a2, mode=mode, delta=delta or 0.0)
+        st.reset(t_init_factor / (L_val + (a2 if a2 > 0 else 0.0)), a1, a2, mode=mode, delta=delta or 0.0,
+                 adaptive_restart=bool(adaptive_restart) and delta is None, restart_threshold=restart_threshold,
+                 tol_step=tol, tol_ratio=tol_ratio, tol_grad=tol if delta is None else 0.0)
         handles.append(st)
     gtimer = _EventTimer(grad_call_times)
     # up to 4 weights: the multi-vector VALU pass where the shape has one; up to 16: the matrix-core pass
@@ -691,4 +695,8 @@ def fista_path(A, b, alphas, t_init_factor: float = 1.0, max_iter: int = 500, *,
                 st.run(max_iter)
         gtimer.stop(ev, max_iter)
     gtimer.flush()
-    return [_core.from_device_vec(st.x_tensor(), like) for st in handles]
+    xs = [_core.from_device_vec(st.x_tensor(), like) for st in handles]
+    if return_info:
+        stats = [st.status() for st in handles]
+        return xs, [(int(s.k), int(s.stopped)) for s in stats]
+    return xs

@@ -94,6 +94,44 @@ class _HipOps:
         return _core.from_device_vec(self.prob.vec_out(x), self.prob.like)
 
 
+class _HipColOps(_HipOps):
+    """COLUMN-sharded fit (very wide A): this rank holds A[:, its columns] and its block of every n-vector.  `fg` exchanges
+    the m-vector residual under the C ABI (fos_gemv_pair_dd on a column-sharded problem); every dot product of the
+    iteration is a sum over the ranks: the five scalars of `stats` cross in one small all-reduce (max|g| in a slot per
+    rank), the direction sums the ranks' partial Gram matrices (fos_lbfgs_direction_cols).  All ranks then take identical
+    decisions on identical numbers."""
+
+    def __init__(self, prob, comm):
+        self.lib = _lib.load()
+        self.prob, self.comm = prob, comm
+        self.n, self.dev = prob.n_dev, prob.device
+        self._stats = torch.zeros(8, dtype=torch.float64, device=self.dev)
+        self._xchg = torch.zeros(4 + comm.world, dtype=torch.float64, device=self.dev)
+        self._work = torch.zeros(64 * 256, dtype=torch.float64, device=self.dev)
+        self._gd = torch.zeros(2, dtype=torch.float64, device=self.dev)
+        self.rr = self._stats[5:6]
+
+    def stats(self, x, g, d):
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.fos_vec_stats_dd(_core.ptr(x), _core.ptr(g), _core.ptr(d), self.n, _core.ptr(self._stats),
+                                                 _core.stream_ptr()), "fos_vec_stats_dd")
+            s, xc = self._stats, self._xchg
+            xc.zero_()
+            xc[0], xc[1], xc[2], xc[3] = s[0], s[1], s[2], s[4]             # x.x, g.d, d.d, ||x||_1: sums over the blocks
+            xc[4 + self.comm.rank] = s[3]                                   # max|g|: one slot per rank
+            self.comm.allreduce(xc)
+            h = xc.cpu().tolist()
+        return [h[0], h[1], h[2], max(h[4:]), h[3], float(self.rr.cpu())]
+
+    def direction(self, g, S, Y, hist, head):
+        d = torch.empty(self.n, dtype=torch.float64, device=self.dev)
+        with self.prob.ctx():
+            _lib.check(self.lib.fos_lbfgs_direction_cols(self.prob.h, _core.ptr(g), _core.ptr(S), _core.ptr(Y), hist, head, _M,
+                                                         _core.ptr(d), _core.ptr(self._gd), _core.ptr(self._work),
+                                                         self._work.numel()), "fos_lbfgs_direction_cols")
+        return d
+
+
 class LBFGSSolver:
     """L-BFGS for Ridge and smooth Elastic-Net, with tiny-α shortcut.   lbfgs.py:7-73"""
 
@@ -147,7 +185,7 @@ class LBFGSSolver:
         self.final_obj_ = float(res.f)                                                # lbfgs.py:72
         return self
 
-    def fit(self, A, b, *, group=None, comm=None, ops=None):
+    def fit(self, A, b, *, group=None, comm=None, ops=None, cols=None):
         """``group`` / ``comm``: A, b are THIS RANK's rows of a row-sharded problem; every ``fg`` all-reduces
         [partial gradient ; partial ||r||^2] (n + 1 doubles) once and all ranks take identical decisions on
         identical numbers, so x stays replicated bit for bit.  ``comm`` (a `distributed.Comm`): the all-reduce runs
@@ -155,6 +193,12 @@ class LBFGSSolver:
         backend): it runs here, between the kernels.  ``ops``: the vector/pass primitives (default: the HIP kernels;
         the gloo CPU test injects a stand-in)."""
         reset_metrics()
+        if cols is not None:
+            # ``cols=(lo, hi, n_total)`` with ``comm=``: COLUMN sharding - A is this rank's columns of all rows, b the whole
+            # vector; x_, iterates_ are this rank's block; the host-side driver below runs replicated on global scalars
+            from .iterative_solvers import _sharded_problem
+            prob, _ = _sharded_problem(A, b, None, comm, None, cols)
+            ops = _HipColOps(prob, comm)
         if ops is None and (group is None or dist.get_world_size(group) == 1):
             return self._fit_native(_HipOps(A, b, comm))
         ops = ops if ops is not None else _HipOps(A, b, comm)

@@ -5,24 +5,19 @@ import torch
 from . import _core, _lib
 
 
-def _scalar(tau, name):
-    if isinstance(tau, (torch.Tensor, np.ndarray)):
-        count = tau.size if isinstance(tau, np.ndarray) else tau.numel()
-        if count != 1:
-            raise ValueError(f"{name}: expected a scalar")
-        return float(tau.reshape(-1)[0])
-    return float(tau)
-
-
 def _is_array(tau):
     if isinstance(tau, np.ndarray):
         return tau.size > 1
     return isinstance(tau, torch.Tensor) and tau.numel() > 1
 
 
-def prox_l1(v, tau):
-    """Soft threshold  sign(v)·max(|v| − τ, 0).   prox_operators.py:3-8.  τ: scalar or an array of v's length
-    (the reference's NumPy expression broadcasts; an array of another shape is rejected here)."""
+def _scalar(tau):
+    return float(tau.reshape(-1)[0]) if isinstance(tau, (torch.Tensor, np.ndarray)) else float(tau)
+
+
+def _apply(name, v, tau, *weights):
+    """One launch of `fos_<name>` (scalar tau) or `fos_<name>_vec` (tau an array of v's length: the reference's NumPy
+    expressions broadcast; an array of another shape is rejected here).  Returns the same kind of object as `v`."""
     lib = _lib.load()
     _core.require_gpu()
     vt = _core.to_device_vec(v)
@@ -30,35 +25,22 @@ def prox_l1(v, tau):
     if _is_array(tau):
         tt = _core.to_device_vec(tau, vt.device)
         if tt.numel() != vt.numel():
-            raise ValueError("prox_l1: array-valued tau must have the length of v")
-        with torch.cuda.device(vt.device):
-            _lib.check(lib.fos_prox_l1_vec(_core.ptr(vt), _core.ptr(tt), _core.ptr(out), vt.numel(), _core.stream_ptr()),
-                       "fos_prox_l1_vec")
-        return _core.from_device_vec(out, v) if not isinstance(v, torch.Tensor) else out
+            raise ValueError(f"{name}: array-valued tau must have the length of v")
+        fn, t_arg = getattr(lib, f"fos_{name}_vec"), _core.ptr(tt)
+    else:
+        fn, t_arg = getattr(lib, f"fos_{name}"), _scalar(tau)
     with torch.cuda.device(vt.device):
-        _lib.check(lib.fos_prox_l1(_core.ptr(vt), _scalar(tau, "prox_l1"), _core.ptr(out), vt.numel(),
-                                   _core.stream_ptr()), "fos_prox_l1")
-    return _core.from_device_vec(out, v) if not isinstance(v, torch.Tensor) else out
+        _lib.check(fn(_core.ptr(vt), t_arg, *(float(w) for w in weights), _core.ptr(out), vt.numel(), _core.stream_ptr()),
+                   fn.__name__)
+    return out if isinstance(v, torch.Tensor) else _core.from_device_vec(out, v)
+
+
+def prox_l1(v, tau):
+    """Soft threshold  sign(v)·max(|v| − τ, 0).   prox_operators.py:3-8.  τ: scalar or an array of v's length."""
+    return _apply("prox_l1", v, tau)
 
 
 def prox_elastic_net(v, tau, alpha1, alpha2):
     """prox_{τ(α₁‖·‖₁ + ½α₂‖·‖²)}(v) = prox_l1(v, τα₁) / (1 + τα₂).   prox_operators.py:10-16.  τ: scalar or an array
-    of v's length (the reference's expression broadcasts)."""
-    lib = _lib.load()
-    _core.require_gpu()
-    vt = _core.to_device_vec(v)
-    out = torch.empty_like(vt)
-    if _is_array(tau):
-        tt = _core.to_device_vec(tau, vt.device)
-        if tt.numel() != vt.numel():
-            raise ValueError("prox_elastic_net: array-valued tau must have the length of v")
-        with torch.cuda.device(vt.device):
-            _lib.check(lib.fos_prox_elastic_net_vec(_core.ptr(vt), _core.ptr(tt), float(alpha1), float(alpha2),
-                                                    _core.ptr(out), vt.numel(), _core.stream_ptr()),
-                       "fos_prox_elastic_net_vec")
-        return _core.from_device_vec(out, v) if not isinstance(v, torch.Tensor) else out
-    with torch.cuda.device(vt.device):
-        _lib.check(lib.fos_prox_elastic_net(_core.ptr(vt), _scalar(tau, "prox_elastic_net"), float(alpha1),
-                                            float(alpha2), _core.ptr(out), vt.numel(), _core.stream_ptr()),
-                   "fos_prox_elastic_net")
-    return _core.from_device_vec(out, v) if not isinstance(v, torch.Tensor) else out
+    of v's length."""
+    return _apply("prox_elastic_net", v, tau, alpha1, alpha2)

@@ -239,8 +239,12 @@ int fos_fista_run_history(fos_fista* f, int iters, double* x_hist, double* hist,
  * two GEMM-shaped products per iteration on the matrix cores for all weights together, R = A Y - b (v_mfma_f32_16x16x4_f32
  * / v_mfma_f32_16x16x32_bf16) and G = A^T R (csrc/gram_batch.hpp).  Results equal running each handle with
  * fos_fista_run (1e-6).  A row-sharded problem (fos_problem_set_comm) takes the matrix-core pass for any number of
- * weights: the 16 partial gradients are summed over the ranks in ONE all-reduce per iteration.  FOS_ERR_UNSUPPORTED when
- * the shape has no such kernel (two-pass path, n <= 64, n > 16384 fp32) or a handle needs data-dependent control: the
+ * weights: the 16 partial gradients are summed over the ranks in ONE all-reduce per iteration.
+ * Handles with data-dependent control (adaptive restart, step / ratio tolerances: iterative_solvers.py:209-221, :235-242)
+ * keep the lockstep from three weights on: momentum and stops are decided on the device per state machine every
+ * iteration (update -> bookkeeping of all weights in one launch -> their y_{k+1}), a stopped weight becomes a masked
+ * column of the block.  FOS_ERR_UNSUPPORTED when the shape has no such kernel (two-pass path, n <= 64, n > 16384 fp32) or
+ * a handle uses the gradient-norm rule (tol_grad: it sits before the update) or a device-held step (backtracking): the
  * caller then runs the handles one by one.
  * SURVEY.md 8(f) rank 3. */
 int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters);
@@ -315,6 +319,11 @@ int fos_vec_axpby_f64(double a, const double* x, double b, const float* y, doubl
  * (any alignment works, through the generic form). */
 int fos_lbfgs_two_loop_dd(const double* g, const double* S, const double* Y, int hist, int head, int cap, int64_t n,
                           double* d_out, void* stream);
+/* The same direction for a COLUMN-SHARDED problem (fos_problem_set_comm_cols): g, S, Y, d are this rank's blocks; the
+ * partial Gram matrices of all ranks are summed by one all-reduce (64 x 256 doubles) between the two kernels, the
+ * coefficient recursion is replicated, gd_out = {g.d, d.d} are global.  work: >= 64 * 256 doubles.  Enqueue-only. */
+int fos_lbfgs_direction_cols(fos_problem* p, const double* g, const double* S, const double* Y, int hist, int head, int cap,
+                             double* d_out, double* gd_out, double* work, int64_t work_doubles);
 /* The same direction d = -H g computed by the whole chip in two launches (the two-loop chain above is bound to ONE
  * workgroup: 35 us at n = 8192 and 10 pairs, 0.9 ms at n = 65536): the Gram matrix of {s_i, y_i, g} by many workgroups,
  * then the recursion on 2*hist+1 coefficients and d as their combination (L-BFGS-B's own compact representation; equal to

@@ -1029,6 +1029,33 @@ def test_fista_path_sixteen_weights_on_the_matrix_cores(fos, kind, m, n, nlam):
     assert _data.rel(_np(x_again[0]), _np(xs[0])) < 1e-6
 
 
+@pytest.mark.parametrize("kind,m,n,nlam", [("f32", 3000, 512, 8), ("bf16", 1500, 1024, 5), ("f32", 900, 2048, 16)])
+def test_fista_path_lockstep_with_restart_and_ratio_stop(fos, kind, m, n, nlam):
+    """Data-dependent control per weight INSIDE the lockstep pass (round 3): adaptive restart and the ratio stop are decided
+    on the device for every state machine every iteration; a stopped weight is a masked column.  Every weight must stop
+    at the oracle's iteration with the oracle's iterate, whatever the others do; the tolerance-with-gradient-rule case
+    (`tol`) falls back to one-by-one runs and must agree as well."""
+    A, b, _ = _data.synth(m, n, 31 + n)
+    At = torch.as_tensor(A.astype(np.float32)).to(torch.bfloat16 if kind == "bf16" else torch.float32).cuda()
+    A = At.to(torch.float64).cpu().numpy()
+    b = b.astype(np.float32).astype(np.float64)
+    prob = fos.prepare(At, b.astype(np.float32))
+    lam = float(np.max(np.abs(A.T @ b)))
+    L = float(np.linalg.norm(A, 2) ** 2)
+    alphas = [(lam * 0.5 * 0.6 ** i, 0.3 if i % 3 == 2 else 0.0) for i in range(nlam)]
+    for kw in (dict(adaptive_restart=True), dict(adaptive_restart=True, restart_threshold=0.9, tol_ratio=0.5),
+               dict(tol_ratio=0.8), dict(tol=1e-3 * lam)):
+        xs, info = fos.fista_path(prob, None, alphas, max_iter=60, L=L, return_info=True, **kw)
+        stops = set()
+        for (a1, a2), x, (k, code) in zip(alphas, xs, info):
+            x_ref, h_ref = orc.fista(A, b, "elasticnet", a1, a2, max_iter=60, L=L, return_history=True, **kw)
+            assert k == len(h_ref["obj"]), (kw, a1, k, len(h_ref["obj"]))
+            assert _data.rel(_np(x), x_ref) < TOL, (kw, a1)
+            stops.add(k)
+        if "tol_ratio" in kw:
+            assert len(stops) > 1 or min(stops) < 60, "the case must exercise a stop"
+
+
 @pytest.mark.parametrize("m,n,nlam", [(4133, 8188, 16), (2100, 16384, 11), (8200, 4096, 16), (4200, 5000, 6)])
 def test_fista_path_one_read_cluster_pass(fos, m, n, nlam):
     """The opt-in one-read form of the matrix-core pass (cluster_pass.hpp: clusters of 4 / 8 / 16 workgroups share row panels,

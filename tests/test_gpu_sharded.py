@@ -354,7 +354,8 @@ def test_one_shot_mesh_allreduce_two_processes(tmp_path):
 # --------------------------------------------------------------------------------------------------
 COL_SHAPE = (600, 2048, 13)
 COL_CASES = [dict(), dict(adaptive_restart=True), dict(tol=0.5), dict(tol_ratio=0.9), dict(return_history=True),
-             dict(return_history=True, adaptive_restart=True, tol_ratio=0.97)]
+             dict(return_history=True, adaptive_restart=True, tol_ratio=0.97),
+             dict(backtracking=True, t_init_factor=2.0), dict(backtracking=True, t_init_factor=1.0, return_history=True)]
 
 
 def _cols_worker(rank, world, port, out_dir):
@@ -388,14 +389,21 @@ def _cols_worker(rank, world, port, out_dir):
             xk = res
         out[f"x{i}"] = xk.cpu().numpy()
         out[f"ngrad{i}"] = np.asarray(fos.get_metrics()["grad_num_calls"])
+        if kw.get("backtracking"):
+            out[f"ls{i}"] = np.asarray(fos.get_metrics()["ls_iters_total"])
     xd = fos.fista_delta(prob, None, "lasso", a1, 0.0, 3.0, max_iter=30, L=L, comm=comm, cols=(lo, hi, n))
     out["xd"] = xd.cpu().numpy()
-    try:
-        fos.fista(prob, None, "lasso", a1, 0.0, max_iter=3, L=L, comm=comm, cols=(lo, hi, n), backtracking=True)
-        out["bt_raises"] = np.asarray(False)
-    except NotImplementedError:
-        out["bt_raises"] = np.asarray(True)
-    from fastoptsolver_amd import _lib
+    # the fp64-accumulating pass (L-BFGS fg) column-sharded: this rank's block of the gradient, the global ||r||^2
+    from fastoptsolver_amd import _core, _lib
+    xg = np.random.default_rng(5).standard_normal(n) * (1.0 + 1e-9)
+    xd64 = torch.as_tensor(xg[lo:hi], dtype=torch.float64, device="cuda")
+    out64 = torch.zeros(hi - lo + 1, dtype=torch.float64, device="cuda")
+    _lib.check(_lib.load().fos_gemv_pair_dd(prob.h, _core.ptr(xd64), 0.3, _core.ptr(out64)))
+    out["dd"] = out64.cpu().numpy()
+    # L-BFGS with the iterate partitioned: fg exchanges the m-vector, the direction the Gram matrices, the scalars one vector
+    sl = fos.LBFGSSolver("ridge", 0.0, a2).fit(prob, None, comm=comm, cols=(lo, hi, n))
+    out["xl"], out["lb_counts"] = sl.x_.cpu().numpy(), np.asarray([sl.nit_, sl.nfev_])
+    out["lb_hist"] = np.asarray(sl.history_)
     refused = 0
     for call in (lambda: prob.replan(no_colblock=True), lambda: prob.power_iter(np.ones(hi - lo, np.float32), 3)):
         try:
@@ -413,7 +421,8 @@ def _cols_worker(rank, world, port, out_dir):
 def test_column_sharding_two_processes(tmp_path):
     """A split by COLUMNS over two ranks (each: all rows, half the columns, the whole b): the concatenated blocks of x
     equal the unsharded oracle for the plain loop, adaptive restart, the three stopping rules (same stopping iteration),
-    the history objective, FISTA-delta, and with L from the column-sharded power iteration."""
+    the history objective, backtracking (round 3: 16 candidates' m-vectors in one all-reduce; same shrink counts),
+    FISTA-delta, the fp64 `fg` pass, and with L from the column-sharded power iteration."""
     import torch.multiprocessing as mp
     world = 2
     mp.spawn(_cols_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
@@ -422,8 +431,16 @@ def test_column_sharding_two_processes(tmp_path):
     a1, a2 = _weights(A, b)
     n = A.shape[1]
     cat = lambda key: np.concatenate([r[k][key] for k in range(world)])       # noqa: E731
-    assert all(bool(rk["bt_raises"]) for rk in r)
     assert all(int(rk["refused"]) == 2 for rk in r)          # replan / local power iteration refuse partial sums
+    xg = np.random.default_rng(5).standard_normal(n) * (1.0 + 1e-9)
+    A32 = A.astype(np.float32).astype(np.float64)
+    g_ref, rr_ref = orc.gram_gradient(A32, xg, b.astype(np.float32).astype(np.float64), 0.3)
+    assert _data.rel(np.concatenate([rk["dd"][:-1] for rk in r]), g_ref) < 1e-12
+    assert all(float(rk["dd"][-1]) == pytest.approx(rr_ref, rel=1e-12) for rk in r)
+    ref_l = orc.LBFGSSolver("ridge", 0.0, a2).fit(A32, b.astype(np.float32).astype(np.float64))
+    assert _data.rel(cat("xl"), ref_l.x_) < TOL
+    assert all(list(rk["lb_counts"]) == [ref_l.nit_, ref_l.nfev_] for rk in r), (r[0]["lb_counts"], ref_l.nit_, ref_l.nfev_)
+    assert np.array_equal(r[0]["lb_hist"], r[1]["lb_hist"]) and np.allclose(r[0]["lb_hist"], ref_l.history_, rtol=1e-7)
     np.random.seed(0)
     L = orc.estimate_lipschitz(A, v0=np.random.randn(n))
     assert _data.rel(cat("x_l"), orc.fista(A, b, "elasticnet", a1, a2, max_iter=5, L=L)) < TOL
@@ -434,6 +451,10 @@ def test_column_sharding_two_processes(tmp_path):
         x_ref = ref[0] if kw.get("return_history") else ref
         assert cat(f"x{i}").shape == (n,) and _data.rel(cat(f"x{i}"), x_ref) < TOL, kw
         assert int(r[0][f"ngrad{i}"]) == int(r[1][f"ngrad{i}"]) == met["grad_num_calls"], kw
+        if kw.get("backtracking"):             # the ranks take identical Armijo decisions - the reference's, up to the
+            ls = int(r[0][f"ls{i}"])           # length of its ~50-halving step-underflow event (fp64 noise regime,
+            assert ls == int(r[1][f"ls{i}"]), kw                      # DESIGN.md 5; iterates and gradient counts are exact)
+            assert abs(ls - met["ls_iters_total"]) <= 8, (kw, ls, met["ls_iters_total"])
         if kw.get("return_history"):
             h_ref = ref[1]
             assert np.array_equal(r[0][f"obj{i}"], r[1][f"obj{i}"]) and len(r[0][f"obj{i}"]) == len(h_ref["obj"]), kw
