@@ -37,7 +37,7 @@ static_assert(BT_COLS % 16 == 0 && BT_A_LOADS >= 1 && BT_X_LOADS >= 1, "tile sha
 
 // Candidate generation: dlt_j (fp64 -> fp32, written in Xp layout) and per-candidate sums.
 // part[wg] = { gd_j (16), dd_j (16), nnz_j (16), ||grad||^2, ||y||^2 }.
-__global__ __launch_bounds__(256) void fista_trial_batch_kernel(GradSrc gsrc, int n, int n_pad,
+static __global__ __launch_bounds__(256) void fista_trial_batch_kernel(GradSrc gsrc, int n, int n_pad,
                                                                const double* __restrict__ x_cur,
                                                                const double* __restrict__ x_prev,
                                                                const FistaScalars* __restrict__ scal, FistaParams prm,
@@ -249,7 +249,7 @@ constexpr int BQ_COLS = 128;                         // Xq is zero-padded to a m
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 // Candidate generation for the bf16 path: same sums as fista_trial_batch_kernel, dlt_j written as three bf16 terms.
-__global__ __launch_bounds__(256) void fista_trial_batch_bf16_kernel(GradSrc gsrc, int n, int n_pad,
+static __global__ __launch_bounds__(256) void fista_trial_batch_bf16_kernel(GradSrc gsrc, int n, int n_pad,
                                                                     const double* __restrict__ x_cur,
                                                                     const double* __restrict__ x_prev,
                                                                     const FistaScalars* __restrict__ scal,
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void fista_trial_batch_bf16_kernel(GradSrc gsr
 }
 
 // Plain [n][16] fp32 candidates -> Xq (three bf16 terms each); stand-alone entry / tests.
-__global__ void xq_pack_kernel(const float* __restrict__ X, int n, int n_pad, int nv, unsigned short* __restrict__ xq) {
+static __global__ void xq_pack_kernel(const float* __restrict__ X, int n, int n_pad, int nv, unsigned short* __restrict__ xq) {
   for (int col = blockIdx.x * 256 + threadIdx.x; col < n_pad; col += gridDim.x * 256)
     for (int j = 0; j < BT_NV; ++j) {
       const float df = (col < n && j < nv) ? X[(int64_t)col * BT_NV + j] : 0.f;

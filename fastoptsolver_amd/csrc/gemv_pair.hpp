@@ -44,7 +44,7 @@ struct YSource {
   const int* stopped;    // device flag: non-zero -> kernel is a no-op (solver already stopped)
   double beta_val;
   const double* yd;      // explicit y in fp64 (L-BFGS iterate); used when y == nullptr and x_cur == nullptr
-  // Column-blocked passes over rows too wide for one workgroup's registers (fos_api.hip "column blocks"); read by the
+  // Column-blocked passes over rows too wide for one workgroup's registers (fos_plan.hip "column blocks"); read by the
   // CB = true instantiations of gemv_pair_kernel only:
   float* res_out;        // nullable: the NEGATED residual of every row, res_out[i] = (res_accum ? res_out[i] : 0) - s_i
   int res_accum;
@@ -163,7 +163,7 @@ __device__ inline double wave_sum(double v) { return wave_sum_dpp(v); }   // fp6
 // YLDS = true (ACC = double only) keeps y in LDS instead (THREADS*K*EPC doubles of dynamic shared memory, up to 128 KiB
 // of the CU's 160 KiB): the geometries for 64 KiB rows would otherwise need y + gradient slice = 256 KiB of the CU's
 // 512 KiB register file plus two row tiles, and spill.  LDS read traffic is 8 bytes per element of A, ~26 B/clk/CU.
-// CB = true is the column-block instantiation (rows wider than any geometry, fos_api.hip "column blocks"): it also
+// CB = true is the column-block instantiation (rows wider than any geometry, fos_plan.hip "column blocks"): it also
 // stores / accumulates the negated residual of every row (YSource::res_out) and honours YSource::slab_stride.  Those are
 // COMPILE-TIME so that the streaming instantiations' steady-state loop carries no exec-masked store block between the
 // post-barrier LDS reads and the next tile's loads (round 2 had them as runtime fields: +52 ISA lines, +10 branches in

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(GB_THREADS) void gram_batch_mfma_bf16_kernel(const 
 }
 
 // y_k of state machine `slot` into the candidate block of product 1: fp32 Xp layout, or three bf16 terms (Xq) for bf16 A.
-__global__ __launch_bounds__(256) void form_y_block_kernel(const double* __restrict__ x_cur, const double* __restrict__ x_prev,
+static __global__ __launch_bounds__(256) void form_y_block_kernel(const double* __restrict__ x_cur, const double* __restrict__ x_prev,
                                                            double beta, int n, int slot, float* __restrict__ xp,
                                                            unsigned short* __restrict__ xq) {
   for (int col = blockIdx.x * 256 + threadIdx.x; col < n; col += gridDim.x * 256) {

@@ -298,7 +298,7 @@ __device__ inline int vl_index(int i, int j, int nb) {          // i <= j
   return i * nb - i * (i - 1) / 2 + (j - i);
 }
 
-__global__ __launch_bounds__(VL_THREADS) void lbfgs_gram_kernel(const double* __restrict__ g, const double* __restrict__ S,
+static __global__ __launch_bounds__(VL_THREADS) void lbfgs_gram_kernel(const double* __restrict__ g, const double* __restrict__ S,
                                                                 const double* __restrict__ Y, int hist, int head, int cap,
                                                                 int64_t n, double* __restrict__ partial) {
   __shared__ double L[VL_NB][VL_COLS + 1];
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(VL_THREADS) void lbfgs_gram_kernel(const double* __
   if (tid < npairs) partial[(int64_t)blockIdx.x * VL_PSTRIDE + tid] = acc;
 }
 
-__global__ __launch_bounds__(VL_THREADS) void lbfgs_combine_kernel(const double* __restrict__ g, const double* __restrict__ S,
+static __global__ __launch_bounds__(VL_THREADS) void lbfgs_combine_kernel(const double* __restrict__ g, const double* __restrict__ S,
                                                                    const double* __restrict__ Y, int hist, int head, int cap,
                                                                    int64_t n, const double* __restrict__ partial, int nparts,
                                                                    double* __restrict__ d_out, double* __restrict__ gd_out) {
@@ -446,10 +446,10 @@ __global__ __launch_bounds__(LB_THREADS) void vec_stats_kernel(const XT* __restr
   }
 }
 
-__global__ void stamp_kernel(unsigned long long* out) { *out = wall_clock64(); }
+static __global__ void stamp_kernel(unsigned long long* out) { *out = wall_clock64(); }
 
 // out3 = { ||x||^2, ||x||_1, 0 }
-__global__ __launch_bounds__(LB_THREADS) void vec_norms_kernel(const float* __restrict__ x, int64_t n,
+static __global__ __launch_bounds__(LB_THREADS) void vec_norms_kernel(const float* __restrict__ x, int64_t n,
                                                                double* __restrict__ out2) {
   __shared__ double lds[2][16];
   double a = 0.0, b = 0.0;
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(LB_THREADS) void vec_norms_kernel(const float* __re
   }
 }
 
-__global__ __launch_bounds__(256) void vec_axpby_kernel(float a, const float* __restrict__ x, float b,
+static __global__ __launch_bounds__(256) void vec_axpby_kernel(float a, const float* __restrict__ x, float b,
                                                         const float* __restrict__ y, float* __restrict__ out,
                                                         int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void vec_axpby_kernel(float a, const float* __
   }
 }
 
-__global__ __launch_bounds__(256) void cast_f64_f32_kernel(const double* __restrict__ in, float* __restrict__ out, int64_t n) {
+static __global__ __launch_bounds__(256) void cast_f64_f32_kernel(const double* __restrict__ in, float* __restrict__ out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = (float)in[i];
 }
 
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void vec_axpby_f64_kernel(double a, const doub
 }
 
 // First trial point of an L-BFGS iteration: x_old = x, x = stp*d + x_old (rounded like vec_axpby_f64_kernel) in one launch.
-__global__ __launch_bounds__(256) void lbfgs_first_trial_kernel(double* __restrict__ x, const double* __restrict__ d,
+static __global__ __launch_bounds__(256) void lbfgs_first_trial_kernel(double* __restrict__ x, const double* __restrict__ d,
                                                                 double stp, double* __restrict__ x_old, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const double xo = x[i];
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void lbfgs_first_trial_kernel(double* __restri
 
 // End of an L-BFGS iteration in one launch: the accepted iterate goes to the record (iter_out, may be NULL) and, when the
 // curvature test kept it, the new correction pair is stored: s = stp * d, y = g - g_old.
-__global__ __launch_bounds__(256) void lbfgs_store_pair_kernel(double stp, const double* __restrict__ d,
+static __global__ __launch_bounds__(256) void lbfgs_store_pair_kernel(double stp, const double* __restrict__ d,
                                                                const double* __restrict__ g,
                                                                const double* __restrict__ g_old, double* __restrict__ s_out,
                                                                double* __restrict__ y_out, const double* __restrict__ x,

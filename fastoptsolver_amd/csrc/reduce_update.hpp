@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 // config 3 - so the sum is spread wide: a workgroup owns 64 columns, 512 threads = 32 column pairs (16-byte loads) x 16
 // slab groups, each group sums every 16th slab and the groups are added in index order.  grid = ceil(n / 64).
 constexpr int SRD_GROUPS = 16, SRD_COLS = 64, SRD_THREADS = SRD_GROUPS * SRD_COLS / 2;
-__global__ __launch_bounds__(SRD_THREADS) void slab_reduce_dd_kernel(const double* __restrict__ slabs, int nslabs, int n,
+static __global__ __launch_bounds__(SRD_THREADS) void slab_reduce_dd_kernel(const double* __restrict__ slabs, int nslabs, int n,
                                                                     int64_t stride, const double* __restrict__ rr_part,
                                                                     int n_rr, double alpha2, const double* __restrict__ y,
                                                                     double* __restrict__ out, const int* stopped = nullptr) {
@@ -363,7 +363,7 @@ struct MultiUpdate {
 };
 // host_beta = 0 (controlled runs): beta comes from each state machine's device scalars and no y is written (beta_{k+1} is
 // decided by fista_finalize_multi_kernel behind this launch; form_y_multi_kernel then fills the block).
-__global__ __launch_bounds__(256) void fista_update_multi_kernel(const float* __restrict__ slabs, int nslabs, int n,
+static __global__ __launch_bounds__(256) void fista_update_multi_kernel(const float* __restrict__ slabs, int nslabs, int n,
                                                                 MultiUpdate mu, FistaParams prm0, float* __restrict__ y_block,
                                                                 int y_mode, int host_beta = 1) {
   const int v = blockIdx.y;
@@ -448,7 +448,7 @@ __device__ inline void fista_finalize_body(const double* __restrict__ part, int 
   if (stop == STOP_NONE && prm.tol_ratio > 0.0 && ratio < prm.tol_ratio) stop = STOP_RATIO;
   scal->stopped = stop;
 }
-__global__ __launch_bounds__(64) void fista_finalize_kernel(const double* __restrict__ part, int nparts,
+static __global__ __launch_bounds__(64) void fista_finalize_kernel(const double* __restrict__ part, int nparts,
                                                            const double* __restrict__ rr_part, int n_rr,
                                                            FistaScalars* __restrict__ scal, FistaParams prm,
                                                            double* __restrict__ hist_row = nullptr) {
@@ -467,7 +467,7 @@ struct MultiControl {
   int adaptive_restart[BT_NV];
   double restart_threshold[BT_NV], tol_step[BT_NV], tol_ratio[BT_NV];
 };
-__global__ __launch_bounds__(64) void fista_finalize_multi_kernel(MultiControl mc, int nparts, FistaParams prm0) {
+static __global__ __launch_bounds__(64) void fista_finalize_multi_kernel(MultiControl mc, int nparts, FistaParams prm0) {
   const int v = blockIdx.x;
   FistaParams prm = prm0;
   prm.adaptive_restart = mc.adaptive_restart[v];
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(64) void fista_finalize_multi_kernel(MultiControl m
   fista_finalize_body(mc.part[v], nparts, nullptr, 0, mc.scal[v], prm, nullptr);
 }
 // force: also write the columns of stopped state machines (the block's first fill)
-__global__ __launch_bounds__(256) void form_y_multi_kernel(MultiControl mc, int n, float* __restrict__ y_block, int y_mode,
+static __global__ __launch_bounds__(256) void form_y_multi_kernel(MultiControl mc, int n, float* __restrict__ y_block, int y_mode,
                                                           int force) {
   const int v = blockIdx.y;
   if (!force && mc.scal[v]->stopped != 0) return;
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void form_y_multi_kernel(MultiControl mc, int 
 
 // Fresh loop state (fos_fista_reset): t = 1, ratio = inf, everything else 0 - written by the device so that the reset
 // only enqueues.
-__global__ void fista_init_scalars_kernel(FistaScalars* __restrict__ scal) {
+static __global__ void fista_init_scalars_kernel(FistaScalars* __restrict__ scal) {
   FistaScalars z{};
   z.t_prev = 1.0;
   z.ratio = INFINITY;
@@ -512,7 +512,7 @@ __global__ void fista_init_scalars_kernel(FistaScalars* __restrict__ scal) {
 // reduced gradient in gbuf and raises the stop flag; the update and finalize kernels behind it are then no-ops.
 // partial_out != nullptr (column-sharded problems): only this rank's sum of squares is written; after the sum over the
 // ranks grad_norm_decide_kernel takes the decision.
-__global__ __launch_bounds__(1024) void grad_norm_stop_kernel(GradSrc gsrc, int n,
+static __global__ __launch_bounds__(1024) void grad_norm_stop_kernel(GradSrc gsrc, int n,
                                                              const double* __restrict__ x_cur,
                                                              const double* __restrict__ x_prev,
                                                              FistaScalars* __restrict__ scal, FistaParams prm,
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(1024) void grad_norm_stop_kernel(GradSrc gsrc, int 
     if (sqrt(s) < prm.tol_grad) scal->stopped = STOP_GRAD;
   }
 }
-__global__ void grad_norm_decide_kernel(const double* __restrict__ total, FistaScalars* __restrict__ scal, FistaParams prm) {
+static __global__ void grad_norm_decide_kernel(const double* __restrict__ total, FistaScalars* __restrict__ scal, FistaParams prm) {
   if (scal->stopped != 0) return;
   scal->gnorm2 = *total;
   if (sqrt(*total) < prm.tol_grad) scal->stopped = STOP_GRAD;
@@ -550,7 +550,7 @@ __global__ void grad_norm_decide_kernel(const double* __restrict__ total, FistaS
 // iteration (tau persists, :197).  No candidate of the batch accepted: the flag STOP_LS_STALL parks the pipeline - every
 // later kernel is a no-op - until the host finishes this search (rare: the reference's own step-underflow regime).
 // bt: folded sums of the candidate kernel { gd_j (16), dd_j (16), nnz_j (16), ||grad||^2, ||y||^2 }, q = bt + 64.
-__global__ void armijo_decide_kernel(const double* __restrict__ bt, FistaScalars* __restrict__ scal, FistaParams prm,
+static __global__ void armijo_decide_kernel(const double* __restrict__ bt, FistaScalars* __restrict__ scal, FistaParams prm,
                                      double eta, double armijo_c, double grad_eps, int nv, int* __restrict__ ls_out,
                                      double* __restrict__ tau_hist, long long slot) {
   if (scal->stopped != 0) return;
@@ -577,18 +577,18 @@ __global__ void armijo_decide_kernel(const double* __restrict__ bt, FistaScalars
   }
 }
 
-__global__ void set_state_tau_kernel(FistaScalars* __restrict__ scal, double tau) { scal->tau = tau; }
+static __global__ void set_state_tau_kernel(FistaScalars* __restrict__ scal, double tau) { scal->tau = tau; }
 // ||A x_k - b||^2 seen by this iteration's gradient pass (the iterate BEFORE the update) -> its slot of the record
-__global__ void record_rr_x_kernel(const FistaScalars* __restrict__ scal, double* __restrict__ slot) {
+static __global__ void record_rr_x_kernel(const FistaScalars* __restrict__ scal, double* __restrict__ slot) {
   if (scal->stopped != 0) return;
   *slot = scal->rr_x;
 }
-__global__ void clear_stall_kernel(FistaScalars* __restrict__ scal) {
+static __global__ void clear_stall_kernel(FistaScalars* __restrict__ scal) {
   if (scal->stopped == STOP_LS_STALL) scal->stopped = STOP_NONE;
 }
 
 // y = (float)(x_cur + beta (x_cur - x_prev)) as one fp32 vector (entry of a lockstep multi-lambda run).
-__global__ __launch_bounds__(256) void form_y_kernel(const double* __restrict__ x_cur, const double* __restrict__ x_prev,
+static __global__ __launch_bounds__(256) void form_y_kernel(const double* __restrict__ x_cur, const double* __restrict__ x_prev,
                                                      double beta, float* __restrict__ y, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
     y[i] = (float)form_y(x_cur[i], x_prev[i], beta);
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256) void form_y_kernel(const double* __restrict__ 
 // Plain runs (no adaptive restart, no stopping tolerance): t_k and beta_k do not depend on the data, the host hands
 // beta_k to the kernels by value and this kernel runs ONCE per fos_fista_run call to bring the device scalars up to
 // date: step norms from the partials of the last two iterations, momentum scalars from the host.
-__global__ __launch_bounds__(64) void fista_finalize_plain_kernel(const double* __restrict__ part_cur,
+static __global__ __launch_bounds__(64) void fista_finalize_plain_kernel(const double* __restrict__ part_cur,
                                                                  const double* __restrict__ part_prev, int nparts,
                                                                  const double* __restrict__ rr_part, int n_rr,
                                                                  FistaScalars* __restrict__ scal, double t_prev,
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(64) void fista_finalize_plain_kernel(const double* 
 // History fold (fos_fista_run_history): block i turns the raw partials of iteration i into
 // hist[i] = { ||A x_{i+1} - b||^2, ||x_{i+1}||_1, ||x_{i+1}||_2^2, ||x_{i+1} - x_i||^2 }.
 // rr2 partials of slot i+1 belong to the iterate produced by iteration i (slot `iters` = the closing residual pass).
-__global__ __launch_bounds__(64) void history_fold_kernel(const double* __restrict__ rr2_slots, int n_rr,
+static __global__ __launch_bounds__(64) void history_fold_kernel(const double* __restrict__ rr2_slots, int n_rr,
                                                          const double* __restrict__ part_slots, int nparts,
                                                          double* __restrict__ hist) {
   const int i = blockIdx.x;
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(64) void history_fold_kernel(const double* __restri
 // out per workgroup: { grad.dlt, ||dlt||^2, #(dlt != 0), ||grad||^2, ||y||^2 }, grad including alpha2*y.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int TRIAL_W = 5;
-__global__ __launch_bounds__(256) void fista_trial_kernel(GradSrc gsrc, int n,
+static __global__ __launch_bounds__(256) void fista_trial_kernel(GradSrc gsrc, int n,
                                                          const double* __restrict__ x_cur,
                                                          const double* __restrict__ x_prev,
                                                          const FistaScalars* __restrict__ scal, FistaParams prm,
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(256) void fista_trial_kernel(GradSrc gsrc, int n,
 // Fold `nparts` rows of `width` doubles (fixed order) into out[width].  One workgroup of 16 waves: wave v folds
 // the columns v, v+16, ... (lanes stride over the rows, butterfly at the end) - deterministic.
 constexpr int FOLD_THREADS = 1024;
-__global__ __launch_bounds__(FOLD_THREADS) void fold_partials_kernel(const double* __restrict__ part, int nparts,
+static __global__ __launch_bounds__(FOLD_THREADS) void fold_partials_kernel(const double* __restrict__ part, int nparts,
                                                                     int width, double* __restrict__ out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int w = wave; w < width; w += FOLD_THREADS / 64) {
@@ -716,18 +716,18 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_partials_kernel(const doubl
 // ---------------------------------------------------------------------------------------------------------
 // Stand-alone prox kernels (prox_operators.py:3-8, :10-16) for the ista() callable path.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void prox_l1_kernel(const float* __restrict__ v, float thr, float* __restrict__ out,
+static __global__ __launch_bounds__(256) void prox_l1_kernel(const float* __restrict__ v, float thr, float* __restrict__ out,
                                                      int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
     out[i] = soft_threshold(v[i], thr);
 }
 // per-element threshold (the reference's prox_l1 broadcasts an array-valued tau: prox_operators.py:8)
-__global__ __launch_bounds__(256) void prox_l1_vec_kernel(const float* __restrict__ v, const float* __restrict__ thr,
+static __global__ __launch_bounds__(256) void prox_l1_vec_kernel(const float* __restrict__ v, const float* __restrict__ thr,
                                                          float* __restrict__ out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
     out[i] = soft_threshold(v[i], thr[i]);
 }
-__global__ __launch_bounds__(256) void prox_enet_kernel(const float* __restrict__ v, float tau, float a1, float a2,
+static __global__ __launch_bounds__(256) void prox_enet_kernel(const float* __restrict__ v, float tau, float a1, float a2,
                                                        float* __restrict__ out, int64_t n) {
   const float thr = tau * a1, inv = 1.0f + tau * a2;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(256) void prox_enet_kernel(const float* __restrict_
 }
 
 // per-element tau (the reference's expression broadcasts an array-valued tau: prox_operators.py:15-16)
-__global__ __launch_bounds__(256) void prox_enet_vec_kernel(const float* __restrict__ v, const float* __restrict__ tau,
+static __global__ __launch_bounds__(256) void prox_enet_vec_kernel(const float* __restrict__ v, const float* __restrict__ tau,
                                                            float a1, float a2, float* __restrict__ out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
     out[i] = soft_threshold(v[i], tau[i] * a1) / (1.0f + tau[i] * a2);
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256) void prox_enet_vec_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------------------
 // Power iteration tail (iterative_solvers.py:55-56): L = ||w||, v = w / L.  One workgroup.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void power_normalize_kernel(const float* __restrict__ w, int n,
+static __global__ __launch_bounds__(1024) void power_normalize_kernel(const float* __restrict__ w, int n,
                                                               float* __restrict__ v, double* __restrict__ L_out) {
   __shared__ double ws[16];
   __shared__ double Ls;

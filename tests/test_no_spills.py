@@ -12,11 +12,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.timeout(600)
 def test_library_kernels_do_not_spill(tmp_path):
+    from concurrent.futures import ThreadPoolExecutor
     from fastoptsolver_amd import build
-    src = os.path.join(ROOT, "fastoptsolver_amd", "csrc", "fos_api.hip")
-    cmd = [build.hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-Rpass-analysis=kernel-resource-usage",
-           "-c", "-o", str(tmp_path / "x.o"), src]
-    out = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
+    with ThreadPoolExecutor(max_workers=len(build.UNITS)) as pool:          # the four translation units of the library
+        outs = list(pool.map(lambda u: build.compile_unit(u, extra=["-Rpass-analysis=kernel-resource-usage"],
+                                                          out=str(tmp_path / (u + ".o")), verbose=False).stderr, build.UNITS))
+    out = "\n".join(outs)
     kernels, cur = {}, None
     for line in out.splitlines():
         m = re.search(r"remark:\s+Function Name:\s+(\S+)", line)
