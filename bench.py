@@ -413,8 +413,11 @@ def mfma_reference(device):
                 e1.record()
                 e1.synchronize()
                 best = min(best, e0.elapsed_time(e1) * 1e3 / 40)
+            reads = 1 if prob.plan()["cluster"] else 2        # the planner's one-read cluster form (fp32, 4096 / 8192 columns)
             leg["path_16_weights"] = dict(us_per_iteration=best, us_per_weight_iteration=best / 16,
-                                          a_reads_per_iteration=2, hbm_frac_on_two_reads=2.0 * m * n * esz / (best * 1e-6) / (HBM_PEAK_GBPS * 1e9),
+                                          form="one-read cluster pass" if reads == 1 else "two products (A read twice)",
+                                          a_reads_per_iteration=reads,
+                                          hbm_frac_on_those_reads=reads * m * n * esz / (best * 1e-6) / (HBM_PEAK_GBPS * 1e9),
                                           mfma_util_committed_pmc=pmc[kind]["path_mfma_util"])
         leg["instruction"], leg["pmc_source"] = pmc[kind]["instruction"], pmc[kind]["source"]
         out[kind] = leg

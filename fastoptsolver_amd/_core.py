@@ -172,13 +172,14 @@ class Problem:
         plan["interleave"] = (flags >> 5) & 1     # streaming pass: rows dealt round-robin to the workgroups
         return plan
 
-    def replan(self, no_resident=False, no_tall=False, no_wide=False, no_colblock=False, cluster=False, interleave=None):
-        """Re-run the planner with kernel families switched off - or, ``cluster=True``, with the one-read cluster form of
-        the multi-weight pass switched on - (fos_problem_replan): tests and A/B measurements.
+    def replan(self, no_resident=False, no_tall=False, no_wide=False, no_colblock=False, cluster=None, interleave=None):
+        """Re-run the planner with kernel families switched off; ``cluster`` / ``interleave``: True / False force the
+        one-read cluster form of the multi-weight pass / the round-robin row order on or off, None leaves the planner's
+        choice (fos_problem_replan): tests and A/B measurements.
         Call before creating Fista handles on this problem."""
         flags = ((_lib.PLAN_NO_RESIDENT if no_resident else 0) | (_lib.PLAN_NO_TALL if no_tall else 0) |
                  (_lib.PLAN_NO_WIDE if no_wide else 0) | (_lib.PLAN_NO_COLBLOCK if no_colblock else 0) |
-                 (_lib.PLAN_CLUSTER if cluster else 0) |
+                 (0 if cluster is None else (_lib.PLAN_CLUSTER if cluster else _lib.PLAN_NO_CLUSTER)) |
                  (0 if interleave is None else (_lib.PLAN_INTERLEAVE if interleave else _lib.PLAN_NO_INTERLEAVE)))
         with self.ctx():
             _lib.check(self.lib.fos_problem_replan(self.h, flags), "fos_problem_replan")

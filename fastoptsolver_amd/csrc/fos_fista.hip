@@ -416,11 +416,16 @@ static int run_multi_mfma(fos_fista* const* fs, int nv, int iters, bool controll
   if (rc) return rc;
   const bool is_bf16 = p->dtype == FOS_BF16;
   const int64_t esz = is_bf16 ? 2 : 4;
-  // One-read form (cluster_pass.hpp), on request (FOS_PLAN_CLUSTER): fp32, 2049..16384 columns in strips of 1024 -> 4, 8
-  // or 16 members per cluster, all CUs busy, at least 8 panels per cluster.  Anything else takes the two-product form
-  // below, which is also the default: the hand-off chain of the cluster form is exposed under HBM load.
-  if (!p->rbuf16 && p->cp_on && !is_bf16 && p->ncu % 8 == 0) {
-    const int cs_need = (int)((p->n + fos::CP_W - 1) / fos::CP_W);
+  // One-read form (cluster_pass.hpp): fp32, 2049..16384 columns in strips of 1024 -> 4, 8 or 16 members per cluster, all
+  // CUs busy, at least 8 panels per cluster; FOS_PLAN_CLUSTER / FOS_PLAN_NO_CLUSTER force it on (where served) / off.
+  // Planner default (profiles/r03_cluster_crossover.md, 16 weights, us per iteration, two products -> one read): the
+  // one-read form wins where every member of a cluster has a full 1024-column strip and the matrix is large -
+  // 131072 x 4096 826 -> 640, 524288 x 4096 3306 -> 2407, 65536 x 8192 670 -> 643, 262144 x 8192 2668 -> 2430 - ties at
+  // 32768 x 8192 and loses with idle members (6144 columns +10 %, 3072 +5 %) and at 16 members (131072 x 16384 +5 %).
+  const int cs_need = (int)((p->n + fos::CP_W - 1) / fos::CP_W);
+  const bool cluster_wins = (p->n == 4096 || p->n == 8192) && p->m * p->n >= (1ll << 29) && !p->comm;
+  const bool want_cluster = p->cp_mode == 1 || (p->cp_mode == 0 && cluster_wins);
+  if (!p->rbuf16 && want_cluster && !is_bf16 && p->ncu % 8 == 0) {
     const int cs = cs_need <= 2 ? 0 : cs_need <= 4 ? 4 : cs_need <= 8 ? 8 : cs_need <= 16 ? 16 : 0;
     if (cs && (p->ncu / 8) % cs == 0 && p->m >= (int64_t)(p->ncu / cs) * fos::CP_ROWS * 8) {
       p->cp_cs = cs;
@@ -491,7 +496,16 @@ static int run_multi_mfma(fos_fista* const* fs, int nv, int iters, bool controll
   for (int it = 0; it < iters; ++it) {
     if ((rc = prof_mark(p, true))) return rc;
     if (p->cp_cs) {
-      if ((rc = launch_cluster_pass(p))) return rc;
+      if ((rc = launch_cluster_pass(p))) {
+        if (p->cp_mode == 1 || it > 0) return rc;
+        (void)hipGetLastError();                 // planner's own choice refused (cooperative launch): two products instead
+        p->cp_cs = 0;
+        p->cp_mode = 2;
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        (void)hipFree(p->rbuf16); (void)hipFree(p->slabs16);       // sized for the cluster form: re-planned by the re-entry
+        p->rbuf16 = p->slabs16 = nullptr;
+        return run_multi_mfma(fs, nv, iters, controlled);
+      }
     } else
     for (int64_t row0 = 0, panel = 0; row0 < p->m; row0 += p->panel_rows, ++panel) {
       const int64_t rows = std::min<int64_t>(p->panel_rows, p->m - row0);
@@ -560,6 +574,13 @@ static int run_multi_mfma(fos_fista* const* fs, int nv, int iters, bool controll
         f->plain_count += 1;
       }
     }
+  }
+  if (p->cp_cs) {        // a cluster member that waited out its bound parked itself and raised the flag: the sums are invalid
+    int bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, p->cp_error, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (bad) return fail(FOS_ERR_STATE, "fos_fista_run_multi: the one-read cluster pass timed out waiting for a member "
+                                        "(results invalid); rerun with FOS_PLAN_NO_CLUSTER");
   }
   for (int v = 0; v < nv && !controlled; ++v) {
     fos_fista* f = fs[v];

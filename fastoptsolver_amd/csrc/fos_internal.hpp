@@ -88,6 +88,7 @@ struct LbfgsWork {
   double* host = nullptr;              // pinned: 16 doubles
   unsigned long long* t_start = nullptr;   // device: wall-clock stamp taken in front of an evaluation
   double ticks_per_ms = 1e5;           // hipDeviceAttributeWallClockRate (kHz)
+  bool pass_stamps = false;           // the pass kernel of this plan stamps its own start (dd_pass_stamps)
   ~LbfgsWork() {
     void* bufs[] = {g, g_old, d, x_old, S, Y, vl, t_start};
     for (void* q : bufs)
@@ -166,7 +167,7 @@ struct fos_problem {
   unsigned* cp_flags = nullptr;
   int* cp_error = nullptr;
   unsigned cp_epoch = 1;
-  bool cp_on = false;                // FOS_PLAN_CLUSTER (opt-in)
+  int cp_mode = 0;                   // 0: planner's choice, 1: FOS_PLAN_CLUSTER, 2: FOS_PLAN_NO_CLUSTER
   // optional kernel timing (fos_problem_profile)
   int profiling = 0;                 // 0 off, N: bracket every N-th launch of the A pass
   int64_t prof_seq = 0;
@@ -232,6 +233,8 @@ int launch_residual_batch(fos_problem* p, int use_b, double* out16, const int* s
 int launch_cluster_pass(fos_problem* p);
 // the fp64-accumulating pass for any y source: out[0..n) = A^T (A y - b) + alpha2*l2vec, out[n] = ||A y - b||^2
 int launch_pass_dd(fos_problem* p, const YSource& ys, double alpha2, const double* l2vec, double* out);
+int gemv_pair_dd_stamped(fos_problem* p, const double* x, double alpha2, double* grad_rr, unsigned long long* t_stamp, bool* stamped);
+int dd_pass_stamps(fos_problem* p, bool* yes);
 // ---- fos_comm.hip ---------------------------------------------------------------------------------------------------
 // in-place sum over the ranks of a communicator on `st`: RCCL, or the one-shot full-mesh kernel (comm.hpp)
 int comm_allreduce(fos_comm* c, void* buf, size_t count, bool f64, hipStream_t st);

@@ -52,13 +52,13 @@ namespace {
 inline int vl_parts(int64_t n) { return (int)std::min<int64_t>((n + fos::VL_COLS - 1) / fos::VL_COLS, fos::VL_MAXPARTS); }
 // d = -H g on the whole chip (lbfgs_kernels.hpp): Gram matrix of the basis, then coefficients + combination
 int launch_direction(const double* g, const double* S, const double* Y, int hist, int head, int cap, int64_t n, double* d_out,
-                     double* gd_out, double* work, hipStream_t st) {
+                     double* gd_out, double* work, hipStream_t st, double* x_step = nullptr, double* x_old = nullptr) {
   const int parts = vl_parts(n);
   hipLaunchKernelGGL(fos::lbfgs_gram_kernel, dim3(parts), dim3(fos::VL_THREADS), 0, st, g, S, Y, hist, head, std::max(cap, 1),
                      n, work);
   const int grid = (int)((n + fos::VL_THREADS - 1) / fos::VL_THREADS);      // one column per thread
   hipLaunchKernelGGL(fos::lbfgs_combine_kernel, dim3(grid), dim3(fos::VL_THREADS), 0, st, g, S, Y, hist, head,
-                     std::max(cap, 1), n, (const double*)work, parts, d_out, gd_out);
+                     std::max(cap, 1), n, (const double*)work, parts, d_out, gd_out, x_step, x_old);
   LAUNCH_CHECK();
   return FOS_OK;
 }
@@ -153,6 +153,12 @@ int fos_lbfgs_minimize(fos_problem* p, double alpha2, int max_iter, double pgtol
     nw.n = n;                                  // complete: a partial allocation is rebuilt by the next call
   }
   LbfgsWork& w = *p->lbfgs;
+  {
+    bool stamps = false;
+    int rcq = dd_pass_stamps(p, &stamps);
+    if (rcq) return rcq;
+    w.pass_stamps = stamps;
+  }
   // The scalars of an evaluation cross to the host in pinned memory the kernels write themselves (no copy engine on the
   // round trip):  [0..4] x.x, g.d, d.d, max|g|, ||x||_1   [5] ||r||^2   [6] g.d and [7] d.d of the newest direction
   // [8] sequence number of the evaluation, stored last (system-scope release): the host polls it rather than waiting for
@@ -181,12 +187,13 @@ int fos_lbfgs_minimize(fos_problem* p, double alpha2, int max_iter, double pgtol
   auto enqueue_fg = [&](const double* xv, double* gv, const double* dv) -> int {
     // device time of the evaluation for the reference's grad_call_times metric: a wall-clock stamp in front of the pass,
     // read back by the statistics kernel behind it (hipEvents cost a 6.5 us bubble each on this stream: kernel trace)
+    // (the streaming fp64 kernel stamps its own start; plans served by other kernels get a one-thread stamp kernel in front)
     const bool timed = fg_ms != nullptr;
-    if (timed) {
+    if (timed && !w.pass_stamps) {
       hipLaunchKernelGGL(fos::stamp_kernel, dim3(1), dim3(1), 0, st, w.t_start);
       LAUNCH_CHECK();
     }
-    int rc = fos_gemv_pair_dd(p, xv, alpha2, gv);
+    int rc = gemv_pair_dd_stamped(p, xv, alpha2, gv, (timed && w.pass_stamps) ? w.t_start : nullptr, nullptr);
     if (rc) return rc;
     seq += 1;
     hipLaunchKernelGGL((fos::vec_stats_kernel<double, double>), dim3(1), dim3(fos::LB_THREADS), 0, st, xv, (const double*)gv,
@@ -226,8 +233,11 @@ int fos_lbfgs_minimize(fos_problem* p, double alpha2, int max_iter, double pgtol
 #define FOS_TL(NQ) hipLaunchKernelGGL((fos::lbfgs_two_loop_kernel<double, NQ>), dim3(1), dim3(fos::LB_THREADS), 0, st, \
                                       (const double*)g, (const double*)w.S, (const double*)w.Y, hist_n, head, M, n, w.d, \
                                       host_dev + 6)
+    // (from the second iteration on the unit first step x_old = x, x += d is written by the combine kernel itself)
+    const bool fused_first_trial = n >= 2048 && nit > 0;
     if (n >= 2048) {                            // whole-chip form: two launches, each one read of the history
-      if ((rc = launch_direction(g, w.S, w.Y, hist_n, head, M, n, w.d, host_dev + 6, w.vl, st))) return rc;
+      if ((rc = launch_direction(g, w.S, w.Y, hist_n, head, M, n, w.d, host_dev + 6, w.vl, st,
+                                 fused_first_trial ? x : nullptr, fused_first_trial ? w.x_old : nullptr))) return rc;
     } else if (vec) FOS_TL(1);
     else FOS_TL(0);
 #undef FOS_TL
@@ -240,8 +250,10 @@ int fos_lbfgs_minimize(fos_problem* p, double alpha2, int max_iter, double pgtol
       if (w.host[6] >= 0.0) return finish(f, gmax, nit, 3);          // not a descent direction and no memory to drop
       stp = std::min(1.0 / std::sqrt(w.host[7]), 1e10);
     }
-    hipLaunchKernelGGL(fos::lbfgs_first_trial_kernel, dim3(ax_grid), dim3(256), 0, st, x, (const double*)w.d, stp, w.x_old, n);
-    LAUNCH_CHECK();
+    if (!fused_first_trial) {
+      hipLaunchKernelGGL(fos::lbfgs_first_trial_kernel, dim3(ax_grid), dim3(256), 0, st, x, (const double*)w.d, stp, w.x_old, n);
+      LAUNCH_CHECK();
+    }
     std::swap(g, g_old);                        // g_old holds the gradient at x_old; g receives the trial gradients
     if ((rc = enqueue_fg(x, g, w.d))) return rc;
     if ((rc = wait_fg())) return rc;

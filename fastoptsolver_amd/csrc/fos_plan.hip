@@ -859,7 +859,7 @@ int fos_problem_replan(fos_problem* p, unsigned flags) {
   if (!p) return fail(FOS_ERR_ARG, "fos_problem_replan: null");
   if (p->col_sharded) return fail(FOS_ERR_UNSUPPORTED, "fos_problem_replan: a column-sharded problem keeps its two-phase plan");
   if (flags & ~(unsigned)(FOS_PLAN_NO_RESIDENT | FOS_PLAN_NO_TALL | FOS_PLAN_NO_WIDE | FOS_PLAN_NO_COLBLOCK | FOS_PLAN_CLUSTER |
-                           FOS_PLAN_INTERLEAVE | FOS_PLAN_NO_INTERLEAVE))
+                           FOS_PLAN_INTERLEAVE | FOS_PLAN_NO_INTERLEAVE | FOS_PLAN_NO_CLUSTER))
     return fail(FOS_ERR_ARG, "fos_problem_replan: unknown flag");
   // the multi-lambda workspace follows its own plan (one-read cluster form or two products): rebuilt on first use
   {
@@ -868,8 +868,8 @@ int fos_problem_replan(fos_problem* p, unsigned flags) {
       if (q) (void)hipFree(q);
     p->rbuf16 = p->slabs16 = p->cp_xchg = nullptr; p->cp_flags = nullptr; p->cp_error = nullptr;
     p->cp_cs = p->cp_clusters = 0;
-    p->cp_on = (flags & FOS_PLAN_CLUSTER) != 0;
-    flags &= ~(unsigned)FOS_PLAN_CLUSTER;
+    p->cp_mode = (flags & FOS_PLAN_CLUSTER) ? 1 : (flags & FOS_PLAN_NO_CLUSTER) ? 2 : 0;
+    flags &= ~(unsigned)(FOS_PLAN_CLUSTER | FOS_PLAN_NO_CLUSTER);
   }
   // workspace sized for the old plan (slab stride, fp64 slabs) is dropped and rebuilt
   void* drop[] = {p->slabs, p->rr_part, p->rr2_part, p->slabs_dd, p->rr_dd};
@@ -1094,6 +1094,15 @@ int fosapi::launch_pass_dd(fos_problem* p, const YSource& ys, double alpha2, con
 extern "C" {
 
 int fos_gemv_pair_dd(fos_problem* p, const double* x, double alpha2, double* grad_rr) {
+  return fosapi::gemv_pair_dd_stamped(p, x, alpha2, grad_rr, nullptr, nullptr);
+}
+
+}  // extern "C"
+// fos_gemv_pair_dd; t_stamp (nullable): where the pass leaves the wall clock of its start, *stamped says whether the
+// kernel that serves this plan does (the streaming fp64 kernel; the others leave it to the caller's stamp kernel)
+int fosapi::gemv_pair_dd_stamped(fos_problem* p, const double* x, double alpha2, double* grad_rr, unsigned long long* t_stamp,
+                                 bool* stamped) {
+  if (stamped) *stamped = false;
   if (!p || !x || !grad_rr) return fail(FOS_ERR_ARG, "fos_gemv_pair_dd: null");
   if (p->resident) {                           // small problem: one launch, fp64 throughout (resident.hpp)
     if (p->dtype == FOS_F32)
@@ -1107,8 +1116,25 @@ int fos_gemv_pair_dd(fos_problem* p, const double* x, double alpha2, double* gra
     return FOS_OK;
   }
   YSource ys{nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, x};
+  if (t_stamp != nullptr) {
+    bool ok = false;
+    int rc = dd_pass_stamps(p, &ok);
+    if (rc) return rc;
+    if (ok) ys.t_stamp = t_stamp;
+    if (stamped) *stamped = ok;
+  }
   return launch_pass_dd(p, ys, alpha2, x, grad_rr);
 }
+// whether the kernel behind fos_gemv_pair_dd on this plan writes YSource::t_stamp (the streaming fp64 kernel does)
+int fosapi::dd_pass_stamps(fos_problem* p, bool* yes) {
+  *yes = false;
+  if (p->resident) return FOS_OK;
+  int rc = ensure_dd(p);
+  if (rc) return rc;
+  *yes = p->dd_entry != nullptr && !p->tall && !p->col_sharded;
+  return FOS_OK;
+}
+extern "C" {
 
 int fos_residual_objective(fos_problem* p, const float* x, double* out3) {
   if (!p || !x || !out3) return fail(FOS_ERR_ARG, "fos_residual_objective: null");

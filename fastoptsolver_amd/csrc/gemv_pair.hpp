@@ -49,6 +49,9 @@ struct YSource {
   float* res_out;        // nullable: the NEGATED residual of every row, res_out[i] = (res_accum ? res_out[i] : 0) - s_i
   int res_accum;
   int64_t slab_stride;   // floats between consecutive slab rows (0 = n): a block writes its columns of full-width slabs
+  // nullable: the first thread of the grid leaves the constant-rate wall clock here when the kernel starts (the L-BFGS
+  // driver times its evaluations with it instead of hipEvents or a stamp kernel of its own: each costs ~5 us of stream time)
+  unsigned long long* t_stamp;
 };
 
 __device__ inline double source_beta(const YSource& ys) {
@@ -182,6 +185,7 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
   static_assert(!YLDS || (sizeof(ACC) == 8 && !DUAL), "YLDS is the fp64 form without DUAL");
 
   if (ys.stopped != nullptr && *ys.stopped != 0) return;
+  if (ys.t_stamp != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *ys.t_stamp = wall_clock64();
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;

@@ -337,7 +337,11 @@ static __global__ __launch_bounds__(VL_THREADS) void lbfgs_gram_kernel(const dou
 static __global__ __launch_bounds__(VL_THREADS) void lbfgs_combine_kernel(const double* __restrict__ g, const double* __restrict__ S,
                                                                    const double* __restrict__ Y, int hist, int head, int cap,
                                                                    int64_t n, const double* __restrict__ partial, int nparts,
-                                                                   double* __restrict__ d_out, double* __restrict__ gd_out) {
+                                                                   double* __restrict__ d_out, double* __restrict__ gd_out,
+                                                                   double* __restrict__ x_step = nullptr,
+                                                                   double* __restrict__ x_old = nullptr) {
+  // x_step (fos_lbfgs_minimize, every iteration but the first): the first trial point of the line search rides along -
+  // x_old = x, x = 1.0*d + x (L-BFGS-B's unit first step, products and sum rounded as lbfgs_first_trial_kernel does)
   __shared__ double G[VL_NB][VL_NB + 1];
   __shared__ double delta_s[VL_NB];
   const int nb = 2 * hist + 1, tid = threadIdx.x;
@@ -401,6 +405,11 @@ static __global__ __launch_bounds__(VL_THREADS) void lbfgs_combine_kernel(const 
 #pragma unroll
     for (int r = 0; r < VL_NB; ++r) acc += (r < nb ? delta_s[r] : 0.0) * bv[r];
     d_out[col] = -acc;
+    if (x_step != nullptr) {
+      const double xo = x_step[col];
+      x_old[col] = xo;
+      x_step[col] = __dadd_rn(__dmul_rn(1.0, -acc), xo);
+    }
   }
 }
 

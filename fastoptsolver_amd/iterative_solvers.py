@@ -148,39 +148,32 @@ def _armijo_accepts(tr, t_k, smooth_a2, grad_eps=8.0 * _EPS32):
 # ---------------------------------------------------------------------
 # shared FISTA / FISTA-Δ / fused-ISTA driver
 # ---------------------------------------------------------------------
-def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backtracking=False, eta=0.5,
-           max_iter=500, tol=0.0, tol_ratio=0.0, adaptive_restart=False, restart_threshold=1.0,
-           grad_tol_check=False, history=None, history_obj=None, x0=None, check_every=None, log=None,
-           batch_trials=True, reducer=None, state=None):
-    """Run the state machine.  Device-driven when nothing needs a per-iteration host decision,
-    host-driven otherwise (grad-norm stop ref:179, backtracking ref:183-197, history ref:224-232)."""
-    st = state if state is not None else _core.Fista(prob)      # `state`: a stand-in with the same interface (CPU tests)
-    x0_dev = None if x0 is None else _core.to_device_vec(x0, prob.device).double()   # padded by Fista.reset
-    # reducer: split-form sharding - the all-reduce sits between the gradient and the update, so the host drives
-    host_driven = backtracking or history is not None or log is not None or reducer is not None
-    # gradient-norm stop (ref:179): on the device (fos_fista_params.tol_grad) when the run is enqueue-only, by the host
-    # between grad() and update() when the host drives anyway
-    device_loop = reducer is None                               # every such configuration has an enqueue-only form
-    dev_grad_stop = grad_tol_check and tol > 0.0 and (not host_driven or device_loop)
-    st.reset(tau, alpha1, alpha2, mode=mode, prox_kind=prox_kind, delta=delta, adaptive_restart=adaptive_restart,
-             restart_threshold=restart_threshold, tol_step=tol if tol > 0.0 else 0.0,
-             tol_ratio=tol_ratio if tol_ratio > 0.0 else 0.0, x0=x0_dev, **({"tol_grad": tol} if dev_grad_stop else {}))
-    gtimer = getattr(st, "make_timer", _EventTimer)(grad_call_times)     # stand-in states bring a host timer
-    smooth_a2 = alpha2 if (prox_kind == _lib.PROX_L1 and alpha2 > 0) else 0.0
-    use_batch = batch_trials
-    # Backtracking decides on a cancelling sum (grad.dlt): take the gradient from the fp64-accumulating pass then
-    # (not in split-form sharding, where the fp32 gbuf is what travels through torch.distributed)
-    grad_eps = 8.0 * _EPS32
-    if backtracking and reducer is None and hasattr(st, "set_precise"):
-        st.set_precise(True)
-        grad_eps = 64.0 * _EPS64
+class _Run:
+    """One solver run: the state machine, what the caller asked for, and the metric / history sinks.  Each execution
+    strategy is a method that returns True when it ran the whole job and False when this problem / plan has no such form
+    (the dispatcher `_drive` then tries the next one)."""
 
-    if not host_driven:
-        stops_possible = tol > 0.0 or tol_ratio > 0.0
-        chunk = max_iter if not stops_possible else max(1, int(check_every or 8))
+    def __init__(self, prob, like, st, *, tau, eta, max_iter, tol, tol_ratio, backtracking, grad_tol_check, history,
+                 history_obj, log, check_every, reducer, smooth_a2, grad_eps, batch_trials):
+        self.prob, self.like, self.st = prob, like, st
+        self.tau, self.eta, self.max_iter, self.tol, self.tol_ratio = tau, eta, max_iter, tol, tol_ratio
+        self.backtracking, self.grad_tol_check = backtracking, grad_tol_check
+        self.history, self.history_obj, self.log = history, history_obj, log
+        self.check_every, self.reducer = check_every, reducer
+        self.smooth_a2, self.grad_eps, self.use_batch = smooth_a2, grad_eps, batch_trials
+        self.gtimer = getattr(st, "make_timer", _EventTimer)(grad_call_times)     # stand-in states bring a host timer
+        self.recording = history is not None or log is not None
+        # ista passes x0 itself as `like`
+        self.as_tensor = like.tensor if hasattr(like, "tensor") else _core.is_tensor(like)
+
+    # ---- 1. nothing needs the host per iteration: enqueue everything, poll for stops -------------------------------
+    def enqueue_only(self):
+        st, gtimer = self.st, self.gtimer
+        stops_possible = self.tol > 0.0 or self.tol_ratio > 0.0
+        chunk = self.max_iter if not stops_possible else max(1, int(self.check_every or 8))
         done = 0
-        while done < max_iter:
-            todo = min(chunk, max_iter - done)
+        while done < self.max_iter:
+            todo = min(chunk, self.max_iter - done)
             ev = gtimer.start()
             st.run(todo)
             gtimer.stop(ev, todo)
@@ -192,56 +185,56 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
             # only the iterations that really ran count as gradient calls, plus the gradient whose norm ended the run
             s_end = st.status()
             del grad_call_times[int(s_end.k) + (1 if s_end.stopped == _lib.STOP_GRAD else 0):]
-        return st
+        return True
 
-    # Small problems (A fits one CU's LDS): every host-driven feature - backtracking, gradient-norm stop, history, ISTA
-    # log - runs inside ONE launch of the LDS-resident loop; the host only unpacks what the device recorded.
-    if max_iter > 0 and reducer is None:
+    # ---- 2. small problems (A fits one CU's LDS): every host-driven feature - backtracking, gradient-norm stop, history,
+    #         ISTA log - runs inside ONE launch of the LDS-resident loop; the host only unpacks what the device recorded
+    def resident(self):
+        st, gtimer, like = self.st, self.gtimer, self.like
         ev = gtimer.start()
         ls_t0 = time.perf_counter()
-        res = st.run_resident(max_iter, backtracking=backtracking, eta=eta, armijo_c=C,
-                              grad_tol=tol if (grad_tol_check and tol > 0.0) else 0.0,
-                              record=history is not None or log is not None)
-        if res is not None:
-            k = res["done"]
-            # one gradient per completed iteration, plus the one whose norm ended the run (ref:173-180)
-            ngrad = k + (1 if st.status().stopped == _lib.STOP_GRAD else 0)
-            gtimer.stop(ev, max(ngrad, 1))
-            gtimer.flush()
-            del grad_call_times[ngrad:]
-            if backtracking:                                     # ref:183-197: one search per completed iteration
-                share = (time.perf_counter() - ls_t0) / max(k, 1)
-                ls_call_iters.extend(int(v) for v in res["ls"])
-                ls_call_times.extend([share] * k)                # the device does not time its phases: equal shares
-            if history is not None or log is not None:
-                hs = res["hist"].cpu().numpy()
-                xs = res["x"]
-                as_tensor = like.tensor if hasattr(like, "tensor") else _core.is_tensor(like)    # ista passes x0 itself
-                rows = [_core.from_device_vec(xs[i], like) for i in range(k)] if as_tensor else list(xs.cpu().numpy())
-                if history is not None:
-                    history["x"].extend(rows)
-                    history["obj"].extend(history_obj(float(r[0]), float(r[2]), float(r[1])) for r in hs)
-                if log is not None:
-                    log["x"].extend(rows)
-                    log["t"].extend(res["taus"])
-                    log["delta"].extend(float(math.sqrt(r[3])) for r in hs)
-            return st
-        gtimer.pending.clear()
+        res = st.run_resident(self.max_iter, backtracking=self.backtracking, eta=self.eta, armijo_c=C,
+                              grad_tol=self.tol if (self.grad_tol_check and self.tol > 0.0) else 0.0,
+                              record=self.recording)
+        if res is None:
+            gtimer.pending.clear()
+            return False
+        k = res["done"]
+        # one gradient per completed iteration, plus the one whose norm ended the run (ref:173-180)
+        ngrad = k + (1 if st.status().stopped == _lib.STOP_GRAD else 0)
+        gtimer.stop(ev, max(ngrad, 1))
+        gtimer.flush()
+        del grad_call_times[ngrad:]
+        if self.backtracking:                                    # ref:183-197: one search per completed iteration
+            share = (time.perf_counter() - ls_t0) / max(k, 1)
+            ls_call_iters.extend(int(v) for v in res["ls"])
+            ls_call_times.extend([share] * k)                    # the device does not time its phases: equal shares
+        if self.recording:
+            hs = res["hist"].cpu().numpy()
+            xs = res["x"]
+            rows = [_core.from_device_vec(xs[i], like) for i in range(k)] if self.as_tensor else list(xs.cpu().numpy())
+            if self.history is not None:
+                self.history["x"].extend(rows)
+                self.history["obj"].extend(self.history_obj(float(r[0]), float(r[2]), float(r[1])) for r in hs)
+            if self.log is not None:
+                self.log["x"].extend(rows)
+                self.log["t"].extend(res["taus"])
+                self.log["delta"].extend(float(math.sqrt(r[3])) for r in hs)
+        return True
 
-    # History without any per-iteration host round trip: x and the objective ingredients are recorded on the device
-    # by the same two kernels of the plain run and read back once (ref:224-232, :319-322).
-    plain = not (mode == _lib.MODE_FISTA and adaptive_restart) and tol == 0.0 and tol_ratio == 0.0
-    if history is not None and log is None and not backtracking and plain and max_iter > 0 and reducer is None:
-        chunk = max(1, min(max_iter, _HISTORY_CHUNK_BYTES // (8 * prob.n_dev)))     # bound the device-side x history
-        done, supported = 0, True
-        while done < max_iter and supported:
-            todo = min(chunk, max_iter - done)
+    # ---- 3. history of a PLAIN run without any per-iteration host round trip: x and the objective ingredients are
+    #         recorded on the device by the same two kernels of the plain run and read back once (ref:224-232, :319-322)
+    def history_plain(self):
+        st, gtimer, prob, like, history = self.st, self.gtimer, self.prob, self.like, self.history
+        chunk = max(1, min(self.max_iter, _HISTORY_CHUNK_BYTES // (8 * prob.n_dev)))    # bound the device-side x history
+        done = 0
+        while done < self.max_iter:
+            todo = min(chunk, self.max_iter - done)
             ev = gtimer.start()
             rec = st.run_history(todo)
             if rec is None:
-                supported = False
                 gtimer.pending.clear()
-                break
+                return False
             gtimer.stop(ev, todo)
             xh, hs = rec
             hs = hs.cpu().numpy()
@@ -249,66 +242,58 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
                 history["x"].extend(_core.from_device_vec(xh[i], like) for i in range(todo))
             else:
                 history["x"].extend(list(xh.cpu().numpy()))
-            history["obj"].extend(history_obj(float(r[0]), float(r[2]), float(r[1])) for r in hs)
+            history["obj"].extend(self.history_obj(float(r[0]), float(r[2]), float(r[1])) for r in hs)
             done += todo
-        if supported:
-            gtimer.flush()
-            return st
+        gtimer.flush()
+        return True
 
-    def refresh_gradient_after_stall():
-        """Sharded problem: the iterations enqueued behind a parked search are no-ops on the device, but their in-place
-        all-reduces still ran - on the parked gradient, which they scaled by the number of ranks each time.  One fresh
-        gradient pass restores it before the host finishes the search (a parked search is a rare event)."""
-        if getattr(prob, "comm", None) is not None:
-            st.grad()
-
-    def search_on_host(t_k, bt_steps):
-        """Armijo search ref:183-197 / :298-312 / :92-108 from step t_k on (bt_steps shrinks already taken)."""
-        nonlocal use_batch
+    # ---- the Armijo search on the host (ref:183-197 / :298-312 / :92-108): used by the host-driven loop and to finish a
+    #      search the device parked (all 16 candidates of a batch rejected: the reference's step-underflow regime)
+    def search_on_host(self, t_k, bt_steps):
+        st, reducer = self.st, self.reducer
         while True:
             # candidates t_k, t_k*eta, ... decided by ONE pass over A on the matrix cores (fos.h); ragged
             # problems (two-pass fallback) evaluate one candidate per pass.
-            rows = st.trial_batch(t_k, eta, _BATCH) if use_batch else None
+            rows = st.trial_batch(t_k, self.eta, _BATCH) if self.use_batch else None
             if rows is None:
-                use_batch = False
+                self.use_batch = False
                 rows = [st.trial(t_k, with_residual=True)]
             if reducer is not None:                        # ||A dlt||^2 = sum over the row blocks; ||r||^2 likewise
                 for tr, q in zip(rows, reducer.sum([tr["q"] for tr in rows])):
                     tr["q"] = q
                     tr["rr_y"] = reducer.rr_global()
             for tr in rows:
-                if _armijo_accepts(tr, t_k, smooth_a2, grad_eps):
+                if _armijo_accepts(tr, t_k, self.smooth_a2, self.grad_eps):
                     return t_k, bt_steps
-                t_k *= eta                                 # ref:195
+                t_k *= self.eta                            # ref:195
                 bt_steps += 1
 
-    # Everything with data-dependent control runs device-driven too - no host round trip per iteration:
+    # ---- 4. data-dependent control on the device - no host round trip per iteration:
     #   backtracking (fos_fista_run_backtracking): gradient, one matrix-core batch of 16 candidates, a decision kernel,
     #     the update with the accepted step, the bookkeeping - all enqueued;
     #   with history / ista's log (fos_fista_run_recorded; also adaptive restart and the stopping rules without
     #     backtracking): iterates and their norms recorded per iteration, ||A x - b||^2 of every iterate out of the NEXT
     #     iteration's gradient pass, the last objective closed by one residual pass.
-    # The host polls every `check_every` iterations for stops and for a parked search (all 16 candidates rejected: the
-    # reference's step-underflow regime), which it finishes itself before handing the loop back to the device.
-    recording = history is not None or log is not None
-    if reducer is None and max_iter > 0 and hasattr(st, "run_recorded") and (recording or backtracking):
-        cap = _HISTORY_CHUNK_BYTES // (8 * prob.n_dev) if recording else max_iter
-        chunk = max(1, min(int(check_every or (16 if recording else 8)), cap))
-        done, started_total, supported, ls_t0 = 0, 0, True, time.perf_counter()
+    # The host polls every `check_every` iterations for stops and for a parked search, which it finishes itself before
+    # handing the loop back to the device.
+    def device_driven(self):
+        st, gtimer, prob, like = self.st, self.gtimer, self.prob, self.like
+        history, log, backtracking, recording = self.history, self.log, self.backtracking, self.recording
+        cap = _HISTORY_CHUNK_BYTES // (8 * prob.n_dev) if recording else self.max_iter
+        chunk = max(1, min(int(self.check_every or (16 if recording else 8)), cap))
+        done, started_total, ls_t0 = 0, 0, time.perf_counter()
         rr_seen, norms = [], []                # rr_seen[t]: residual of the iterate iteration t started from
-        as_tensor = like.tensor if hasattr(like, "tensor") else _core.is_tensor(like)    # ista passes x0 itself
-        while done < max_iter:
-            todo = min(chunk, max_iter - done)
+        while done < self.max_iter:
+            todo = min(chunk, self.max_iter - done)
             ev = gtimer.start()
             if recording:
-                rec = st.run_recorded(todo, backtracking, eta, C, grad_eps, want_rr=history is not None)
+                rec = st.run_recorded(todo, backtracking, self.eta, C, self.grad_eps, want_rr=history is not None)
             else:
-                pair = st.run_backtracking(todo, eta, C, grad_eps)
+                pair = st.run_backtracking(todo, self.eta, C, self.grad_eps)
                 rec = None if pair is None else dict(ls=pair[0], taus=pair[1])
             if rec is None:                                   # this plan has no candidate pass: the host drives
-                supported = False
                 gtimer.pending.clear()
-                break
+                return False
             s = st.status()                                   # synchronises: k, stop / stall flag
             ran = int(s.k) - done
             stalled = s.stopped == _lib.STOP_LS_STALL
@@ -322,19 +307,19 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
                     rr_seen.extend(rec["rr_seen"][:started].cpu().tolist())
                 hs = rec["hist"][:ran].cpu().numpy()
                 xh = prob.vec_out(rec["x"][:ran])
-                rows = [_core.from_device_vec(xh[i], like) for i in range(ran)] if as_tensor else list(xh.cpu().numpy())
+                rows = [_core.from_device_vec(xh[i], like) for i in range(ran)] if self.as_tensor else list(xh.cpu().numpy())
                 if history is not None:
                     history["x"].extend(rows)
                 if log is not None:                            # ista's log (ref:117-120): x, the step used, ||dx||
                     log["x"].extend(rows)
-                    log["t"].extend(rec["taus"][:ran].cpu().tolist() if backtracking else [tau] * ran)
+                    log["t"].extend(rec["taus"][:ran].cpu().tolist() if backtracking else [self.tau] * ran)
                     log["delta"].extend(float(math.sqrt(r[3])) for r in hs)
                 norms.extend((float(r[1]), float(r[2])) for r in hs)
             done += ran
             if stalled:                                       # finish this iteration's search on the host
                 tau = st.resume_after_stall()
-                refresh_gradient_after_stall()
-                tau, steps = search_on_host(tau, _BATCH)
+                tau, steps = self.search_on_host(tau, _BATCH)
+                self.tau = tau
                 ls_call_iters.append(steps)
                 st.set_tau(tau)
                 st.update()
@@ -351,69 +336,117 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
                 done += 1
             if s.stopped != _lib.STOP_NONE:
                 break
-        if supported:
-            gtimer.flush()
-            del grad_call_times[started_total:]
-            if backtracking:
-                share = (time.perf_counter() - ls_t0) / max(len(ls_call_iters), 1)
-                ls_call_times.extend([share] * len(ls_call_iters))    # the device does not time its phases: equal shares
-            # f(x after iteration t) needs ||A x - b||^2 of that iterate: seen by iteration t + 1, or by a closing pass
-            if history is not None:
-                rr_of = rr_seen[1:done + 1]
-                if len(rr_of) < done:
-                    rr_of.append(prob.residual_objective(st.x_tensor())[0])
-                history["obj"].extend(history_obj(rr, x2, x1) for rr, (x1, x2) in zip(rr_of, norms))
-            return st
+        gtimer.flush()
+        del grad_call_times[started_total:]
+        if backtracking:
+            share = (time.perf_counter() - ls_t0) / max(len(ls_call_iters), 1)
+            ls_call_times.extend([share] * len(ls_call_iters))    # the device does not time its phases: equal shares
+        # f(x after iteration t) needs ||A x - b||^2 of that iterate: seen by iteration t + 1, or by a closing pass
+        if history is not None:
+            rr_of = rr_seen[1:done + 1]
+            if len(rr_of) < done:
+                rr_of.append(prob.residual_objective(st.x_tensor())[0])
+            history["obj"].extend(self.history_obj(rr, x2, x1) for rr, (x1, x2) in zip(rr_of, norms))
+        return True
 
-    # History objective f(x_k) without the reference's extra pass per iteration (ref:225-230, :321): the DUAL
-    # gradient pass of iteration k also returns ||A x_k - b||^2, so f(x_k) is appended one iteration late and only
-    # the very last iterate needs a residual pass of its own.
-    def rr_x_of(status):         # ||A x_k - b||^2 over ALL rows (split-form sharding: summed here)
-        return reducer.sum([status.rr_x])[0] if reducer is not None else status.rr_x
+    # ---- 5. the host drives every iteration: split-form sharding over torch.distributed (the all-reduce sits between
+    #         the gradient and the update), generic callables, plans without the candidate pass.
+    # History objective f(x_k) without the reference's extra pass per iteration (ref:225-230, :321): the DUAL gradient
+    # pass of iteration k also returns ||A x_k - b||^2, so f(x_k) is appended one iteration late and only the very last
+    # iterate needs a residual pass of its own.
+    def host_driven(self):
+        st, gtimer, prob, like, reducer = self.st, self.gtimer, self.prob, self.like, self.reducer
+        history, log, tol, tol_ratio = self.history, self.log, self.tol, self.tol_ratio
 
-    owed = None                  # (||x||_1, ||x||_2^2) of the newest iterate whose objective is not recorded yet
-    for _ in range(max_iter):
-        ev = gtimer.start()
-        st.grad(dual=owed is not None)                        # ref:173-175 (alpha2*y is added by the consumers)
-        if reducer is not None:
-            reducer.grad()
-        gtimer.stop(ev)
-        if grad_tol_check and tol > 0.0:                      # ref:179
-            if math.sqrt(st.trial(tau, with_residual=False)["gnorm2"]) < tol:
-                if owed is not None:
-                    history["obj"].append(history_obj(rr_x_of(st.status()), owed[1], owed[0]))
-                    owed = None
+        def rr_x_of(status):         # ||A x_k - b||^2 over ALL rows (split-form sharding: summed here)
+            return reducer.sum([status.rr_x])[0] if reducer is not None else status.rr_x
+
+        owed = None                  # (||x||_1, ||x||_2^2) of the newest iterate whose objective is not recorded yet
+        for _ in range(self.max_iter):
+            ev = gtimer.start()
+            st.grad(dual=owed is not None)                        # ref:173-175 (alpha2*y is added by the consumers)
+            if reducer is not None:
+                reducer.grad()
+            gtimer.stop(ev)
+            if self.grad_tol_check and tol > 0.0:                 # ref:179
+                if math.sqrt(st.trial(self.tau, with_residual=False)["gnorm2"]) < tol:
+                    if owed is not None:
+                        history["obj"].append(self.history_obj(rr_x_of(st.status()), owed[1], owed[0]))
+                        owed = None
+                    break
+            if self.backtracking:                                 # ref:183-197 / ref:298-312 / ref:92-108
+                ls_t0 = time.perf_counter()
+                t_k, bt_steps = self.search_on_host(self.tau, 0)
+                ls_call_times.append(time.perf_counter() - ls_t0)
+                ls_call_iters.append(bt_steps)
+                self.tau = t_k
+                st.set_tau(self.tau)
+            st.update()                                           # ref:200-221
+            if self.recording:
+                xk = st.x_tensor()
+                s = st.status()
+                if history is not None:
+                    if owed is not None:
+                        history["obj"].append(self.history_obj(rr_x_of(s), owed[1], owed[0]))
+                    history["x"].append(_core.from_device_vec(xk, like))
+                    owed = (s.xnorm1, s.xnorm2)
+                if log is not None:
+                    log["x"].append(_core.from_device_vec(xk, like))
+                    log["t"].append(self.tau)
+                    log["delta"].append(s.this_step)
+            else:
+                s = st.status() if (tol > 0.0 or tol_ratio > 0.0) else None
+            if s is not None and s.stopped != _lib.STOP_NONE:     # ref:238, :242
                 break
-        if backtracking:                                      # ref:183-197 / ref:298-312 / ref:92-108
-            ls_t0 = time.perf_counter()
-            t_k, bt_steps = search_on_host(tau, 0)
-            ls_call_times.append(time.perf_counter() - ls_t0)
-            ls_call_iters.append(bt_steps)
-            tau = t_k
-            st.set_tau(tau)
-        st.update()                                           # ref:200-221
-        if history is not None or log is not None:
-            xk = st.x_tensor()
-            s = st.status()
-            if history is not None:
-                if owed is not None:
-                    history["obj"].append(history_obj(rr_x_of(s), owed[1], owed[0]))
-                history["x"].append(_core.from_device_vec(xk, like))
-                owed = (s.xnorm1, s.xnorm2)
-            if log is not None:
-                log["x"].append(_core.from_device_vec(xk, like))
-                log["t"].append(tau)
-                log["delta"].append(s.this_step)
-        else:
-            s = st.status() if (tol > 0.0 or tol_ratio > 0.0) else None
-        if s is not None and s.stopped != _lib.STOP_NONE:     # ref:238, :242
-            break
-    if owed is not None:
-        rr, x2, x1 = prob.residual_objective(st.x_tensor())
-        if reducer is not None:
-            rr = reducer.sum([rr])[0]
-        history["obj"].append(history_obj(rr, x2, x1))
-    gtimer.flush()
+        if owed is not None:
+            rr, x2, x1 = prob.residual_objective(st.x_tensor())
+            if reducer is not None:
+                rr = reducer.sum([rr])[0]
+            history["obj"].append(self.history_obj(rr, x2, x1))
+        gtimer.flush()
+        return True
+
+
+def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backtracking=False, eta=0.5,
+           max_iter=500, tol=0.0, tol_ratio=0.0, adaptive_restart=False, restart_threshold=1.0,
+           grad_tol_check=False, history=None, history_obj=None, x0=None, check_every=None, log=None,
+           batch_trials=True, reducer=None, state=None):
+    """Run the state machine with the first execution strategy of `_Run` that serves this configuration: device-driven
+    wherever nothing needs a per-iteration host decision, host-driven otherwise (split-form sharding, ref:179 / :183-197 /
+    :224-232 on plans without the device forms)."""
+    st = state if state is not None else _core.Fista(prob)      # `state`: a stand-in with the same interface (CPU tests)
+    x0_dev = None if x0 is None else _core.to_device_vec(x0, prob.device).double()   # padded by Fista.reset
+    # reducer: split-form sharding - the all-reduce sits between the gradient and the update, so the host drives
+    host_needed = backtracking or history is not None or log is not None or reducer is not None
+    # gradient-norm stop (ref:179): on the device (fos_fista_params.tol_grad) when the run is enqueue-only, by the host
+    # between grad() and update() when the host drives anyway
+    device_loop = reducer is None                               # every such configuration has an enqueue-only form
+    dev_grad_stop = grad_tol_check and tol > 0.0 and (not host_needed or device_loop)
+    st.reset(tau, alpha1, alpha2, mode=mode, prox_kind=prox_kind, delta=delta, adaptive_restart=adaptive_restart,
+             restart_threshold=restart_threshold, tol_step=tol if tol > 0.0 else 0.0,
+             tol_ratio=tol_ratio if tol_ratio > 0.0 else 0.0, x0=x0_dev, **({"tol_grad": tol} if dev_grad_stop else {}))
+    # Backtracking decides on a cancelling sum (grad.dlt): take the gradient from the fp64-accumulating pass then
+    # (not in split-form sharding, where the fp32 gbuf is what travels through torch.distributed)
+    grad_eps = 8.0 * _EPS32
+    if backtracking and reducer is None and hasattr(st, "set_precise"):
+        st.set_precise(True)
+        grad_eps = 64.0 * _EPS64
+    run = _Run(prob, like, st, tau=tau, eta=eta, max_iter=max_iter, tol=tol, tol_ratio=tol_ratio, backtracking=backtracking,
+               grad_tol_check=grad_tol_check, history=history, history_obj=history_obj, log=log, check_every=check_every,
+               reducer=reducer, smooth_a2=alpha2 if (prox_kind == _lib.PROX_L1 and alpha2 > 0) else 0.0,
+               grad_eps=grad_eps, batch_trials=batch_trials)
+    if not host_needed:
+        run.enqueue_only()
+        return st
+    on_device = reducer is None and max_iter > 0
+    if on_device and run.resident():
+        return st
+    plain = not (mode == _lib.MODE_FISTA and adaptive_restart) and tol == 0.0 and tol_ratio == 0.0
+    if on_device and history is not None and log is None and not backtracking and plain and run.history_plain():
+        return st
+    if on_device and hasattr(st, "run_recorded") and (run.recording or backtracking) and run.device_driven():
+        return st
+    run.host_driven()
     return st
 
 

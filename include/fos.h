@@ -33,11 +33,13 @@ enum { FOS_STOP_NONE = 0, FOS_STOP_STEP = 1, FOS_STOP_RATIO = 2, FOS_STOP_GRAD =
 
 enum { FOS_PLAN_NO_RESIDENT = 1, FOS_PLAN_NO_TALL = 2, FOS_PLAN_NO_WIDE = 4, FOS_PLAN_NO_COLBLOCK = 8,
        FOS_PLAN_CLUSTER = 16,     /* fos_problem_replan; FOS_PLAN_CLUSTER OPTS IN to the one-read cluster form of the
-                                     multi-weight matrix-core pass (csrc/cluster_pass.hpp: cooperative launch, fp32,
-                                     2049..16384 columns; measured 6 % faster at 65536 x 8192, slower at 16384 columns) */
+                                     multi-weight matrix-core pass wherever it is served (csrc/cluster_pass.hpp:
+                                     cooperative launch, fp32, 2049..16384 columns) */
        FOS_PLAN_INTERLEAVE = 32,  /* rows of the streaming pass dealt round-robin to the workgroups (all CUs read one
                                      contiguous window) instead of one contiguous block per workgroup ...           */
-       FOS_PLAN_NO_INTERLEAVE = 64 /* ... or never; neither bit: the planner's default for the shape */ };
+       FOS_PLAN_NO_INTERLEAVE = 64, /* ... or never; neither bit: the planner's default for the shape */
+       FOS_PLAN_NO_CLUSTER = 128    /* never the one-read cluster form (neither cluster bit: the planner takes it where it
+                                       measured ahead - fp32, exactly 4096 or 8192 columns, >= 2 GiB, unsharded) */ };
 
 typedef struct fos_problem fos_problem;   /* A, b, launch plan, workspace            */
 typedef struct fos_comm fos_comm;         /* communicator of a row-sharded problem   */
@@ -164,8 +166,9 @@ int fos_problem_profile_read(fos_problem* p, double* ms_total, int64_t* launches
  * Replaces iterative_solvers.py:54, :173-175, :292-294 and lbfgs.py:46-51.  A is read ONCE. */
 int fos_gemv_pair(fos_problem* p, const float* y, float alpha2, float* grad, double* rr_out);
 
-/* The same with the iterate y given in fp64 (n doubles): the L-BFGS driver keeps x in fp64 like the FISTA state;
- * y is rounded once to fp32 for the pass over A on the fused path and kept in fp64 on the two-pass path. */
+/* LEGACY (round-1 generation; no longer called by the Python layer, kept so that the ABI only grows): the same with the
+ * iterate y given in fp64 (n doubles), rounded once to fp32 for the pass over A on the fused path.  The L-BFGS `fg` is
+ * fos_gemv_pair_dd (fp64 accumulation, y never rounded). */
 int fos_gemv_pair_f64(fos_problem* p, const double* y, double alpha2, float* grad, double* rr_out);
 
 /* The L-BFGS `fg` (lbfgs.py:43-54) at the precision SciPy's optimiser runs it in (lbfgs.py:64): x is n doubles and is
@@ -301,7 +304,11 @@ int fos_fista_get_x(fos_fista* f, double* dst);  /* enqueue copy of x_k (n doubl
 double* fos_fista_x(fos_fista* f);       /* device pointer to x_k (n doubles), borrowed     */
 float* fos_fista_gbuf(fos_fista* f);     /* device pointer to gbuf (n+1 floats), borrowed   */
 
-/* ---- L-BFGS device pieces (the arithmetic behind lbfgs.py:64; spec in SURVEY.md 8c) ----------------- */
+/* ---- L-BFGS device pieces (the arithmetic behind lbfgs.py:64; spec in SURVEY.md 8c) -----------------
+ * Three generations sit side by side because the ABI only grows: fp32 vectors (fos_lbfgs_two_loop, fos_vec_stats,
+ * fos_vec_axpby: round 1; fos_vec_stats / fos_vec_axpby still serve the FISTA front-ends), fp64 iterate with fp32
+ * gradients (*_f64: LEGACY, unused by the product), and fp64 throughout (*_dd, fos_lbfgs_direction_dd,
+ * fos_lbfgs_minimize: what LBFGSSolver runs). */
 /* K4: d = -H g by the two-loop recursion over the `hist` newest pairs.  S, Y: [cap][n] ring buffers,
  * slot (head + i) % cap holds the i-th oldest pair.  One launch. */
 int fos_lbfgs_two_loop(const float* g, const float* S, const float* Y, int hist, int head, int cap, int64_t n,
