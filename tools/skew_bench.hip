@@ -73,14 +73,13 @@ int main(int argc, char** argv) {
   std::vector<Variant> vs;
   if (n <= 8192) {
     vs.push_back({"t512k4 nb3 blocks      ", launch_variant<512, 4, 2, 3, false, false, false>, ncu});
-    vs.push_back({"t512k4 nb3 blocks 255wg", launch_variant<512, 4, 2, 3, false, false, false>, ncu - 1});
-    vs.push_back({"t512k4 nb3 blocks 248wg", launch_variant<512, 4, 2, 3, false, false, false>, ncu - 8});
-    vs.push_back({"t512k4 nb3 SKEW        ", launch_variant<512, 4, 2, 3, false, false, true>, ncu});
     vs.push_back({"t512k4 nb3 IL          ", launch_variant<512, 4, 2, 3, true, false, false>, ncu});
     vs.push_back({"t512k4 nb2 DRAIN       ", launch_variant<512, 4, 2, 2, false, true, false>, ncu});
-    vs.push_back({"t512k4 nb2 DRAIN SKEW  ", launch_variant<512, 4, 2, 2, false, true, true>, ncu});
-    vs.push_back({"t512k4 nb4 blocks      ", launch_variant<512, 4, 2, 4, false, false, false>, ncu});
-    vs.push_back({"t512k4 nb4 SKEW        ", launch_variant<512, 4, 2, 4, false, false, true>, ncu});
+    vs.push_back({"t512k4 nb3 DRAIN       ", launch_variant<512, 4, 2, 3, false, true, false>, ncu});
+    vs.push_back({"t1024k2 r1 nb2 DRAIN   ", launch_variant<1024, 2, 4, 2, false, true, false>, ncu});
+    vs.push_back({"t1024k2 r1 nb3         ", launch_variant<1024, 2, 4, 3, false, false, false>, ncu});
+    vs.push_back({"t1024k2 r1 nb3 DRAIN   ", launch_variant<1024, 2, 4, 3, false, true, false>, ncu});
+    vs.push_back({"t1024k2 r1 nb4 DRAIN   ", launch_variant<1024, 2, 4, 4, false, true, false>, ncu});
   } else {
     vs.push_back({"t1024k4 DRAIN blocks      ", launch_variant<1024, 4, 4, 2, false, true, false>, ncu});
     vs.push_back({"t1024k4 DRAIN blocks 255wg", launch_variant<1024, 4, 4, 2, false, true, false>, ncu - 1});
