@@ -301,9 +301,14 @@ class Fista:
         with self.prob.ctx():
             _lib.check(self.lib.fos_fista_reset(self.h, C.byref(p), ptr(x0)), "fos_fista_reset")
 
-    def set_precise(self, on=True):
-        """Split-form gradient from the fp64-accumulating pass at the unrounded y_k (fos_fista_set_precise)."""
+    def set_precise(self, on=True, own_buffer=False):
+        """Split-form gradient from the fp64-accumulating pass at the unrounded y_k (fos_fista_set_precise).
+        own_buffer: keep [gradient ; ||r||^2] in a torch tensor of this object (`gbuf64`, n_dev + 4 doubles) so that a
+        split-form reducer can sum it over the ranks between grad() and its consumers (fos_fista_set_gbuf64)."""
         with self.prob.ctx():
+            if on and own_buffer and getattr(self, "gbuf64", None) is None:
+                self.gbuf64 = torch.zeros(self.prob.n_dev + 4, dtype=torch.float64, device=self.prob.device)
+                _lib.check(self.lib.fos_fista_set_gbuf64(self.h, ptr(self.gbuf64)), "fos_fista_set_gbuf64")
             _lib.check(self.lib.fos_fista_set_precise(self.h, int(bool(on))), "fos_fista_set_precise")
         self.precise = bool(on)
 

@@ -83,6 +83,7 @@ SIGNATURES = {
     "fos_fista_reset": (_i32, [_vp, C.POINTER(FistaParams), _vp]),
     "fos_fista_set_tau": (_i32, [_vp, _f64]),
     "fos_fista_set_precise": (_i32, [_vp, _i32]),
+    "fos_fista_set_gbuf64": (_i32, [_vp, _vp]),
     "fos_fista_run": (_i32, [_vp, _i32]),
     "fos_fista_history_workspace": (_i64, [_vp, _i32]),
     "fos_fista_run_history": (_i32, [_vp, _i32, _vp, _vp, _vp]),

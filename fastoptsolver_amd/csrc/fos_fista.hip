@@ -30,7 +30,7 @@ int fos_fista_create(fos_problem* p, fos_fista** out) {
 
 int fos_fista_destroy(fos_fista* f) {
   if (!f) return FOS_OK;
-  void* bufs[] = {f->x_cur, f->x_prev, f->dlt, f->scal, f->out5, f->part2, f->ynext, f->gbuf64, f->folded};
+  void* bufs[] = {f->x_cur, f->x_prev, f->dlt, f->scal, f->out5, f->part2, f->ynext, f->gbuf64_owned ? f->gbuf64 : nullptr, f->folded};
   for (void* q : bufs)
     if (q) (void)hipFree(q);
   delete f;
@@ -93,8 +93,21 @@ static fos::GradSrc grad_src(const fos_fista* f) {
 
 int fos_fista_set_precise(fos_fista* f, int on) {
   if (!f) return fail(FOS_ERR_ARG, "fos_fista_set_precise: null");
-  if (on && !f->gbuf64) HIP_TRY(hipMalloc(&f->gbuf64, (size_t)(f->p->n + 4) * sizeof(double)));
+  if (on && !f->gbuf64) {
+    HIP_TRY(hipMalloc(&f->gbuf64, (size_t)(f->p->n + 4) * sizeof(double)));
+    f->gbuf64_owned = true;
+  }
   f->precise = on != 0;
+  return FOS_OK;
+}
+
+int fos_fista_set_gbuf64(fos_fista* f, double* buf) {
+  if (!f) return fail(FOS_ERR_ARG, "fos_fista_set_gbuf64: null");
+  if (buf && (reinterpret_cast<uintptr_t>(buf) & 15u)) return fail(FOS_ERR_ARG, "fos_fista_set_gbuf64: misaligned");
+  if (f->gbuf64 && f->gbuf64_owned) (void)hipFree(f->gbuf64);
+  f->gbuf64 = buf;
+  f->gbuf64_owned = false;
+  if (!buf) f->precise = false;
   return FOS_OK;
 }
 

@@ -199,6 +199,7 @@ struct fos_fista {
   double* folded = nullptr;          // column-sharded: the 4 update sums of an iteration, folded and summed over the ranks
   bool tau_on_device = false;        // FistaScalars::tau is authoritative (device-driven backtracking ran since the last set_tau / reset)
   double* gbuf64 = nullptr;          // n + 4 doubles: [gradient ; ||r||^2]
+  bool gbuf64_owned = false;         // allocated by fos_fista_set_precise (false: the caller's, fos_fista_set_gbuf64)
   double* out5 = nullptr;            // device
   int nupd = 0;                      // workgroups of the update kernel
 };

@@ -144,15 +144,25 @@ const MenuEntry* wide_entry() { return &kWideF32; }
 template <typename T, int NC, int LOAD, bool WITH_G, bool DUAL>
 void tall_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, float* slabs,
                  double* rr_part, double* rr2_part, int nwg, hipStream_t st) {
-  // the staged float4 copy streams one contiguous span: non-temporal (8000000 x 5: 61 -> 70 % of 8 TB/s, tools/tall_bench)
-  hipLaunchKernelGGL((fos::gemv_tall_kernel<T, NC, LOAD, WITH_G, DUAL, float, LOAD == fos::TL_STAGE4>), dim3(nwg),
-                     dim3(fos::TL_THREADS), 0, st, reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part, rr2_part);
+  // The staged float4 copy streams one contiguous span: non-temporal once the matrix outgrows the 256 MiB Infinity Cache
+  // (32000000 x 5: 71.8 -> 82.2 % of 8 TB/s); below that the cached form keeps the re-reads of a solver loop in the
+  // cache (8000000 x 5 = 160 MB: 32.9 us cached, 34.7 us non-temporal).  tools/tall_bench.
+  if (LOAD == fos::TL_STAGE4 && m * (int64_t)n * (int64_t)sizeof(T) > (192ll << 20))
+    hipLaunchKernelGGL((fos::gemv_tall_kernel<T, NC, LOAD, WITH_G, DUAL, float, LOAD == fos::TL_STAGE4>), dim3(nwg),
+                       dim3(fos::TL_THREADS), 0, st, reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part, rr2_part);
+  else
+    hipLaunchKernelGGL((fos::gemv_tall_kernel<T, NC, LOAD, WITH_G, DUAL, float, false>), dim3(nwg), dim3(fos::TL_THREADS), 0, st,
+                       reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part, rr2_part);
 }
 template <typename T, int NC, int LOAD>
 void tall_launch_dd(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, double* slabs,
                     double* rr_part, int nwg, hipStream_t st) {
-  hipLaunchKernelGGL((fos::gemv_tall_kernel<T, NC, LOAD, true, false, double, LOAD == fos::TL_STAGE4>), dim3(nwg),
-                     dim3(fos::TL_THREADS), 0, st, reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part, (double*)nullptr);
+  if (LOAD == fos::TL_STAGE4 && m * (int64_t)n * (int64_t)sizeof(T) > (192ll << 20))
+    hipLaunchKernelGGL((fos::gemv_tall_kernel<T, NC, LOAD, true, false, double, LOAD == fos::TL_STAGE4>), dim3(nwg),
+                       dim3(fos::TL_THREADS), 0, st, reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part, (double*)nullptr);
+  else
+    hipLaunchKernelGGL((fos::gemv_tall_kernel<T, NC, LOAD, true, false, double, false>), dim3(nwg), dim3(fos::TL_THREADS), 0, st,
+                       reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part, (double*)nullptr);
 }
 template <typename T, bool VEC>
 void tallq_launch_dd(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, double* slabs,

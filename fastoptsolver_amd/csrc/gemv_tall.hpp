@@ -70,8 +70,16 @@ __global__ __launch_bounds__(TL_THREADS) void gemv_tall_kernel(const T* __restri
   constexpr int NPRE = STAGE4 ? (NC * RPI + 3) / 4 : NC * RPI;          // float4s / floats per thread and block
   typedef typename std::conditional<STAGE4, f32x4, float>::type PreT;
   PreT pre[STAGE ? NPRE : 1];
+  // b of the prefetched block travels with it (round 3): loaded at consume time it put a whole global-memory latency on
+  // the critical path of every 512-row block - the one thing in this loop that nothing overlapped
+  float bpre[STAGE ? RPI : 1];
   auto prefetch = [&](int64_t row0) {
     if constexpr (STAGE) {
+#pragma unroll
+      for (int u = 0; u < RPI; ++u) {
+        const int64_t row = row0 + u * TL_THREADS + tid;
+        bpre[u] = (row < row_hi && b != nullptr) ? b[row] : 0.f;
+      }
       const int64_t left = row_hi - row0;
       const int count = left <= 0 ? 0 : (int)(left < BLOCK_ROWS ? left : BLOCK_ROWS) * n;
       const T* src = A + row0 * (int64_t)n;                              // lda == n: the block is one contiguous span
@@ -101,7 +109,10 @@ __global__ __launch_bounds__(TL_THREADS) void gemv_tall_kernel(const T* __restri
   };
   prefetch(row_lo);
   for (int64_t row0 = row_lo; row0 < row_hi; row0 += BLOCK_ROWS) {          // uniform loop: TL_STAGE needs the barriers
+    float bcur[STAGE ? RPI : 1];
     if constexpr (STAGE) {
+#pragma unroll
+      for (int u = 0; u < RPI; ++u) bcur[u] = bpre[u];
       __syncthreads();                                                   // the previous block has been consumed
 #pragma unroll
       for (int u = 0; u < NPRE; ++u) {
@@ -122,7 +133,8 @@ __global__ __launch_bounds__(TL_THREADS) void gemv_tall_kernel(const T* __restri
     for (int u = 0; u < RPI; ++u) {
       const int64_t row = row0 + u * TL_THREADS + tid;
       const bool in = row < row_hi;
-      bi[u] = (in && b != nullptr) ? (double)b[row] : 0.0;
+      if constexpr (STAGE) bi[u] = (double)bcur[u];
+      else bi[u] = (in && b != nullptr) ? (double)b[row] : 0.0;
       if constexpr (STAGE) {
         const float* ar = tile_s + (u * TL_THREADS + tid) * n;
 #pragma unroll

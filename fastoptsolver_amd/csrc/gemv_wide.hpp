@@ -52,10 +52,16 @@ __global__ __launch_bounds__(WD_THREADS) void gemv_wide_kernel(const float* __re
   };
   double rr = 0.0;
   u32x4 cur[WD_K], nxt[WD_K];
-  if (row_lo < row_hi) load_row(row_lo, cur);
+  // b_i travels with its row (round 3): read after the barrier it put a memory latency on the critical path of every row
+  float b_cur = 0.f, b_nxt = 0.f;
+  if (row_lo < row_hi) {
+    load_row(row_lo, cur);
+    b_cur = b != nullptr ? b[row_lo] : 0.f;
+  }
   for (int64_t row = row_lo; row < row_hi; ++row) {
     const int64_t rn = row + 1 < row_hi ? row + 1 : row;             // last row: re-read (L2 hit), keeps the loop uniform
     load_row(rn, nxt);
+    b_nxt = b != nullptr ? b[rn] : 0.f;
     float acc = 0.f;
 #pragma unroll
     for (int c = 0; c < WD_K; ++c) {
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(WD_THREADS) void gemv_wide_kernel(const float* __re
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < WD_THREADS / 64; ++w) s += red[pb][w];
-    const float r = s - (b != nullptr ? b[row] : 0.f);
+    const float r = s - b_cur;
     rr += (double)r * (double)r;
     if constexpr (WITH_G) {
 #pragma unroll
@@ -83,6 +89,7 @@ __global__ __launch_bounds__(WD_THREADS) void gemv_wide_kernel(const float* __re
     }
 #pragma unroll
     for (int c = 0; c < WD_K; ++c) cur[c] = nxt[c];
+    b_cur = b_nxt;
   }
   if constexpr (WITH_G) {
 #pragma unroll

@@ -107,13 +107,17 @@ class _GroupReducer:
         import torch.distributed as dist
         self.dist, self.group, self.prob = dist, group, prob
         self.on_device = dist.get_backend(group) == "nccl"
+        self.gbuf64 = None          # precise mode (backtracking): the fp64 [gradient ; ||r||^2] of the state machine
 
     def grad(self):
-        """[partial gradient ; partial ||r||^2] -> global, in gbuf (n + 1 floats: the one exchange per iteration)."""
-        self.dist.all_reduce(self.prob.gbuf[: self.prob.n_dev + 1], op=self.dist.ReduceOp.SUM, group=self.group)
+        """[partial gradient ; partial ||r||^2] -> global, in gbuf (n + 1 floats: the one exchange per iteration; n + 1
+        doubles in precise mode)."""
+        buf = self.gbuf64 if self.gbuf64 is not None else self.prob.gbuf
+        self.dist.all_reduce(buf[: self.prob.n_dev + 1], op=self.dist.ReduceOp.SUM, group=self.group)
 
     def rr_global(self):
-        return float(self.prob.gbuf[self.prob.n_dev])
+        buf = self.gbuf64 if self.gbuf64 is not None else self.prob.gbuf
+        return float(buf[self.prob.n_dev])
 
     def sum(self, vals):
         t = torch.tensor(list(vals), dtype=torch.float64, device=self.prob.device if self.on_device else "cpu")
@@ -425,12 +429,17 @@ def _drive(prob, like, *, mode, prox_kind, alpha1, alpha2, tau, delta=0.0, backt
     st.reset(tau, alpha1, alpha2, mode=mode, prox_kind=prox_kind, delta=delta, adaptive_restart=adaptive_restart,
              restart_threshold=restart_threshold, tol_step=tol if tol > 0.0 else 0.0,
              tol_ratio=tol_ratio if tol_ratio > 0.0 else 0.0, x0=x0_dev, **({"tol_grad": tol} if dev_grad_stop else {}))
-    # Backtracking decides on a cancelling sum (grad.dlt): take the gradient from the fp64-accumulating pass then
-    # (not in split-form sharding, where the fp32 gbuf is what travels through torch.distributed)
+    # Backtracking decides on a cancelling sum (grad.dlt): take the gradient from the fp64-accumulating pass then; in
+    # split-form sharding the state machine keeps it in a tensor of ours and the reducer sums the n + 1 doubles
     grad_eps = 8.0 * _EPS32
-    if backtracking and reducer is None and hasattr(st, "set_precise"):
-        st.set_precise(True)
-        grad_eps = 64.0 * _EPS64
+    if backtracking and hasattr(st, "set_precise"):
+        if reducer is None:
+            st.set_precise(True)
+            grad_eps = 64.0 * _EPS64
+        elif not prob.plan()["resident"]:       # (LDS-resident plans have no split-form fp64 pass: they keep the fp32 gbuf)
+            st.set_precise(True, own_buffer=True)
+            reducer.gbuf64 = st.gbuf64
+            grad_eps = 64.0 * _EPS64
     run = _Run(prob, like, st, tau=tau, eta=eta, max_iter=max_iter, tol=tol, tol_ratio=tol_ratio, backtracking=backtracking,
                grad_tol_check=grad_tol_check, history=history, history_obj=history_obj, log=log, check_every=check_every,
                reducer=reducer, smooth_a2=alpha2 if (prox_kind == _lib.PROX_L1 and alpha2 > 0) else 0.0,

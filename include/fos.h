@@ -213,6 +213,9 @@ int fos_fista_set_tau(fos_fista* f, double tau);
  * wherever those are decidable at all.  The pass costs 5-25 % more than the fp32 one; fista(backtracking=True) turns it
  * on.  Plain fos_fista_run is unaffected. */
 int fos_fista_set_precise(fos_fista* f, int on);
+/* Precise mode with a CALLER-OWNED gradient buffer (n + 4 doubles, 16-byte aligned; NULL returns to fp32): split-form
+ * sharding sums [gradient ; ||r||^2] (n + 1 doubles) over the ranks itself, between fos_fista_grad and the consumers. */
+int fos_fista_set_gbuf64(fos_fista* f, double* buf);
 /* Enqueue `iters` full iterations (gradient, prox, momentum, restart and stop logic all on the device;
  * no host round trip).  Iterations after a device-side stop are no-ops.  :170-242, :289-342 */
 int fos_fista_run(fos_fista* f, int iters);

@@ -203,6 +203,9 @@ def test_two_ranks_every_flag_and_config5_in_miniature(tmp_path):
         x_ref, h_ref = orc.fista(A, b, "elasticnet", a1, a2, max_iter=60, L=L, return_history=True, **kw)
         assert len(r0[f"obj{i}"]) == len(h_ref["obj"]), kw              # same stopping iteration as the unsharded run
         assert _data.rel(r0[f"x{i}"], x_ref) < TOL and np.allclose(r0[f"obj{i}"], h_ref["obj"], rtol=TOL), kw
+        if kw.get("backtracking"):       # split form backtracks on the fp64 gradient too (round 3: n + 1 doubles travel)
+            _, met = orc.fista(A, b, "elasticnet", a1, a2, max_iter=60, L=L, return_metrics=True, **kw)
+            assert abs(int(r0[f"ls{i}"]) - met["ls_iters_total"]) <= 8, (kw, int(r0[f"ls{i}"]), met["ls_iters_total"])
     x_ref, h_ref = orc.fista_delta(A, b, "lasso", a1, 0.0, 3.0, max_iter=40, L=L, return_history=True)
     assert _data.rel(r0["xd"], x_ref) < TOL and np.allclose(r0["objd"], h_ref["obj"], rtol=TOL)
     Aq = torch.as_tensor(A.astype(np.float32)).to(torch.bfloat16).to(torch.float64).numpy()

@@ -12,6 +12,7 @@ Writes gpurun_out/profile_shapes_plan.json: the order of the segments with the a
 import json
 import os
 import sys
+import time
 
 import torch
 
@@ -33,6 +34,8 @@ SHAPES = [
     ("tall 4000000x16 f32 (row per thread)", 4000000, 16, "f32", ("f32",)),
     ("tall 4000000x32 f32 (chunk per lane, 8 lanes per row)", 4000000, 32, "f32", ("f32",)),
     ("tall 8000000x5 f32 (LDS-staged rows)", 8000000, 5, "f32", ("f32",)),
+    ("tall 32000000x5 f32 (LDS-staged rows)", 32000000, 5, "f32", ("f32",)),
+    ("262144x8192 bf16", 262144, 8192, "bf16", ("f32", "dd")),
 ]
 
 
@@ -66,6 +69,7 @@ def main():
                              dtype=kind, launches=LAUNCHES, bytes=m * n * s + 4 * m + 8 * n, plan=prob.plan()))
         del prob, A, b
         torch.cuda.empty_cache()
+        time.sleep(2.0)          # returning GiBs to the driver costs the next kernels 3-6 % for seconds (profiles/r03_row_order.md)
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "profile_shapes_plan.json")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     json.dump(plan, open(out, "w"), indent=1)
