@@ -280,13 +280,20 @@ def test_random_regularisation_paths(fos, seed):
     L = float(np.linalg.norm(A64, "fro") ** 2) or 1.0
     alphas = [(lam * float(rng.choice([0.5, 0.1, 0.01])) * 0.8 ** i, float(rng.choice([0.0, 0.5]))) for i in range(nlam)]
     delta = float(rng.choice([0.0, 0.0, 3.5]))
-    xs = fos.fista_path(fos.prepare(At, b32), None, alphas, max_iter=iters, L=L, **({"delta": delta} if delta else {}))
+    # round 3: data-dependent control inside the lockstep (adaptive restart, ratio stop) on a third of the FISTA draws
+    ctl = {}
+    if not delta and rng.random() < 0.5:
+        ctl = dict(adaptive_restart=bool(rng.random() < 0.7), restart_threshold=float(rng.choice([1.0, 0.9])),
+                   tol_ratio=float(rng.choice([0.0, 0.6, 0.9])))
+    xs, info = fos.fista_path(fos.prepare(At, b32), None, alphas, max_iter=iters, L=L, return_info=True, **ctl,
+                              **({"delta": delta} if delta else {}))
     assert len(xs) == nlam
-    for (a1, a2), x in zip(alphas, xs):
+    for (a1, a2), x, (k_done, _code) in zip(alphas, xs, info):
         if delta:
             x_ref = orc.fista_delta(A64, b, "elasticnet", a1, a2, delta, max_iter=iters, L=L)
         else:
-            x_ref = orc.fista(A64, b, "elasticnet", a1, a2, max_iter=iters, L=L)
+            x_ref, h_ref = orc.fista(A64, b, "elasticnet", a1, a2, max_iter=iters, L=L, return_history=True, **ctl)
+            assert k_done == len(h_ref["obj"]), (seed, m, n, kind, nlam, iters, a1, a2, ctl, k_done, len(h_ref["obj"]))
         x = x.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(x) else np.asarray(x)
         den = float(np.linalg.norm(x_ref))
-        assert np.linalg.norm(x - x_ref) <= 1e-5 * den + 1e-12, (seed, m, n, kind, nlam, iters, a1, a2, delta)
+        assert np.linalg.norm(x - x_ref) <= 1e-5 * den + 1e-12, (seed, m, n, kind, nlam, iters, a1, a2, delta, ctl)
