@@ -528,8 +528,7 @@ def main():
 
     # The riders of the default N=1 run go FIRST (2 GiB each), the 64 GiB headline last.
     target_ref = None
-    if world == 1:
-        settle(4.0)        # a process that ended just before this one (a test suite, another bench) is still being released
+    settle(4.0)            # a process that ended just before this one (a test suite, the previous N) is still being released
     if default_run:
         try:
             r2 = run_workload("cfg2", args, rank, world, device, steps=200, warmup=10,
