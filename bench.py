@@ -437,6 +437,56 @@ def mfma_reference(device):
     return out
 
 
+def fused_reference(device):
+    """north_star's literal wording of the step - "GEMV pair with CDNA4 MFMA and LDS-staged A tiles, fused in one launch with
+    the soft-threshold prox and the FISTA momentum update so the iterate x stays resident" - as its own measurement:
+    fos_fista_run_fused (csrc/fused_step.hpp: ONE persistent launch per run, 4-row panels staged through LDS, the row dots on
+    v_mfma_f32_4x4x1_16B_f32, prox + momentum by the workgroup that owns the columns, its slice of x_k, x_{k-1} in LDS) at
+    cfg2, next to the default two-launch VALU step on the same problem.  Opt-in (FOS_PLAN_FUSED_MFMA): the default is faster."""
+    import fastoptsolver_amd as fos
+    from fastoptsolver_amd import _core
+    from fastoptsolver_amd.operators import vec_stats
+    cfg = WORKLOADS["cfg2"]
+    m, n = cfg["m"], cfg["n"]
+    A, b = make_shard(cfg, 0, m, device)
+    prob = fos.prepare(A, b)
+    atb = prob.gemv_pair(torch.zeros(n, device=device), 0.0)
+    a1 = cfg["a1_frac"] * vec_stats(None, atb, None)[3]
+    np.random.seed(0)
+    v0 = torch.from_numpy(np.random.randn(n).astype(np.float32)).to(device)
+    L = fos.prepare(A, None).power_iter(v0)[0]
+    out = {}
+    xs = {}
+    for name in ("two_launch_valu", "one_launch_mfma_lds"):
+        st = _core.Fista(prob)
+        st.reset(1.0 / L, a1, 0.0)
+        run = st.run if name == "two_launch_valu" else st.run_fused
+        if run(10) is False:
+            return dict(error="fos_fista_run_fused does not serve this shape")
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run(200)
+            e1.record()
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1) * 1e3 / 200)
+        us = float(np.median(times))
+        xs[name] = st.x_tensor()
+        out[name] = dict(us_per_iteration=us, iterations_per_second=1e6 / us,
+                         whole_step_frac=bytes_per_iter(m, n, "f32") / (us * 1e-6) / (HBM_PEAK_GBPS * 1e9), launches_per_run=None)
+        del st
+    out["two_launch_valu"]["launches_per_run"] = "2 per iteration"
+    out["one_launch_mfma_lds"]["launches_per_run"] = "1 per call (200 iterations each here), 2 grid-wide barriers per iteration"
+    out["iterate_rel_diff_after_1010_iterations"] = float((xs["one_launch_mfma_lds"] - xs["two_launch_valu"]).norm() /
+                                                        xs["two_launch_valu"].norm())
+    out["workload"] = f"cfg2 ({m}x{n} f32, lasso), 1 GPU; median of 5 x 200 iterations by HIP events"
+    del prob, A, b
+    torch.cuda.empty_cache()
+    return out
+
+
 def load_traffic(workload):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass (profiles/)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -566,6 +616,15 @@ def main():
             mfma_ref = dict(error=str(exc)[:200])
         settle(3.0)
 
+    # north_star's literal one-launch MFMA / LDS-staged step, measured next to the default (opt-in plan)
+    fused_ref = None
+    if default_run:
+        try:
+            fused_ref = fused_reference(device)
+        except Exception as exc:
+            fused_ref = dict(error=str(exc)[:200])
+        settle(3.0)
+
     res = run_workload(name, args, rank, world, device, args.steps, args.warmup,
                        want_cpu=not args.no_cpu_baseline, dist=dist, repeats=args.repeats)
 
@@ -618,6 +677,7 @@ def main():
             "target_ref": target_ref,
             "lbfgs_ref": lbfgs_ref,
             "mfma_ref": mfma_ref,
+            "fused_ref": fused_ref,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -170,17 +170,21 @@ class Problem:
         plan["colblock"] = (flags >> 3) & 1       # rows wider than any single-pass kernel: column blocks, two phases
         plan["cluster"] = (flags >> 4) & 1        # multi-lambda pass: one-read cluster form planned (after its first run)
         plan["interleave"] = (flags >> 5) & 1     # streaming pass: rows dealt round-robin to the workgroups
+        plan["fused_mfma"] = (flags >> 6) & 1     # opt-in: plain runs take the one-launch persistent step
         return plan
 
-    def replan(self, no_resident=False, no_tall=False, no_wide=False, no_colblock=False, cluster=None, interleave=None):
+    def replan(self, no_resident=False, no_tall=False, no_wide=False, no_colblock=False, cluster=None, interleave=None,
+               fused_mfma=False):
         """Re-run the planner with kernel families switched off; ``cluster`` / ``interleave``: True / False force the
         one-read cluster form of the multi-weight pass / the round-robin row order on or off, None leaves the planner's
-        choice (fos_problem_replan): tests and A/B measurements.
+        choice; ``fused_mfma=True`` opts plain runs in to the one-launch persistent step (fos_fista_run_fused)
+        (fos_problem_replan): tests and A/B measurements.
         Call before creating Fista handles on this problem."""
         flags = ((_lib.PLAN_NO_RESIDENT if no_resident else 0) | (_lib.PLAN_NO_TALL if no_tall else 0) |
                  (_lib.PLAN_NO_WIDE if no_wide else 0) | (_lib.PLAN_NO_COLBLOCK if no_colblock else 0) |
                  (0 if cluster is None else (_lib.PLAN_CLUSTER if cluster else _lib.PLAN_NO_CLUSTER)) |
-                 (0 if interleave is None else (_lib.PLAN_INTERLEAVE if interleave else _lib.PLAN_NO_INTERLEAVE)))
+                 (0 if interleave is None else (_lib.PLAN_INTERLEAVE if interleave else _lib.PLAN_NO_INTERLEAVE)) |
+                 (_lib.PLAN_FUSED_MFMA if fused_mfma else 0))
         with self.ctx():
             _lib.check(self.lib.fos_problem_replan(self.h, flags), "fos_problem_replan")
 
@@ -318,6 +322,16 @@ class Fista:
     def run(self, iters):
         with self.prob.ctx():
             _lib.check(self.lib.fos_fista_run(self.h, int(iters)), "fos_fista_run")
+
+    def run_fused(self, iters):
+        """`iters` plain iterations in ONE persistent launch (fos_fista_run_fused: LDS-staged panels, row dots on the matrix
+        cores, the owned slice of the iterate resident in LDS).  False when this problem / configuration is not served."""
+        with self.prob.ctx():
+            rc = self.lib.fos_fista_run_fused(self.h, int(iters))
+        if rc == -4:
+            return False
+        _lib.check(rc, "fos_fista_run_fused")
+        return True
 
     def run_history(self, iters):
         """Device-resident history run: (x_hist [iters, n] float64, hist [iters, 4] float64 =

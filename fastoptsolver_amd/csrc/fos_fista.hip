@@ -1,8 +1,27 @@
 // libfos_hip.so, translation unit 3 of 4 - the FISTA / ISTA / FISTA-delta state machine of the C ABI (include/fos.h):
 // fused, split, recorded, backtracking, resident and lockstep (multi-lambda) runs.  iterative_solvers.py:65-344.
 #include "fos_internal.hpp"
+#include "fused_step.hpp"
 
 using namespace fosapi;
+
+template <int NQ>
+static int launch_fused(const fos::FusedArgs& a, int G, size_t lds, hipStream_t st) {
+  auto kern = fos::fista_fused_kernel<NQ>;
+  static std::atomic<uint64_t> done{0};
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    done.fetch_or(bit, std::memory_order_release);
+  }
+  // a plain launch: G = #CUs workgroups of 512 threads and ~136 KiB of LDS are co-resident by grid size (one per CU), which
+  // is all hipLaunchCooperativeKernel would check; every grid-wide wait in the kernel is bounded
+  hipLaunchKernelGGL(kern, dim3(G), dim3(fos::FZ_THREADS), lds, st, a);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
 
 extern "C" {
 
@@ -380,6 +399,10 @@ int fos_fista_run(fos_fista* f, int iters) {
   // Plain run: no data-dependent control (adaptive restart / stopping tolerances).  t_k and beta_k are then a fixed
   // sequence: the host passes beta_k to both kernels by value, and the scalar bookkeeping kernel runs once per call
   // instead of once per iteration (two launches per iteration instead of three).
+  if (plain_run(f) && p->fused_on && !f->precise && !f->prm.tau_from_state) {      // opt-in: the one-launch persistent step
+    const int rcf = fos_fista_run_fused(f, iters);
+    if (rcf != FOS_ERR_UNSUPPORTED) return rcf;
+  }
   if (plain_run(f)) {
     bool stopped = false;
     int rc0 = refresh_host_scalars(f, &stopped);
@@ -417,6 +440,101 @@ int fos_fista_run(fos_fista* f, int iters) {
     LAUNCH_CHECK();
     if ((rc = launch_finalize(f, n_rr))) return rc;
   }
+  return FOS_OK;
+}
+
+// The step in ONE persistent launch with the row dots on the matrix cores and A staged through LDS (fused_step.hpp):
+// BASELINE north_star's literal design, opt-in (the two-launch VALU step measures faster).  Plain runs only.
+int fos_fista_run_fused(fos_fista* f, int iters) {
+  if (!f || iters < 0) return fail(FOS_ERR_ARG, "fos_fista_run_fused: bad argument");
+  fos_problem* p = f->p;
+  const int G = p->ncu;
+  if (p->dtype != FOS_F32 || p->path != 0 || p->tall || p->colblock || p->resident || p->comm || p->n % 2048 != 0 ||
+      p->n > 8192 || p->lda % 4 != 0 || (reinterpret_cast<uintptr_t>(p->A) & 15u) || p->m < 8 * (int64_t)G ||
+      (p->n + G - 1) / G > fos::FZ_OWN_MAX)
+    return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_fused: fp32 A, n in {2048, 4096, 6144, 8192}, aligned rows, m >= 8 x CUs, unsharded");
+  if (!plain_run(f) || f->precise || f->prm.tau_from_state)
+    return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_fused: plain runs only (no adaptive restart, tolerances, device-held step)");
+  if (iters == 0) return FOS_OK;
+  int rc = flush_pending(f);
+  if (rc) return rc;
+  bool stopped = false;
+  if ((rc = refresh_host_scalars(f, &stopped))) return rc;
+  if (stopped) return FOS_OK;
+  // workspace: G slabs (the planner's are reused when it planned G workgroups), barrier words, beta sequence, partials
+  if (G > p->slab_cap) {
+    if (p->slabs) (void)hipFree(p->slabs);
+    p->slabs = nullptr; p->slab_cap = 0;
+    HIP_TRY(hipMalloc(&p->slabs, (size_t)G * p->n * sizeof(float)));
+    p->slab_cap = G;
+  }
+  if (G > p->rr_cap) {
+    if (p->rr_part) (void)hipFree(p->rr_part);
+    if (p->rr2_part) (void)hipFree(p->rr2_part);
+    p->rr_part = p->rr2_part = nullptr; p->rr_cap = 0;
+    HIP_TRY(hipMalloc(&p->rr_part, (size_t)G * sizeof(double)));
+    HIP_TRY(hipMalloc(&p->rr2_part, (size_t)G * sizeof(double)));
+    p->rr_cap = G;
+  }
+  if (!p->fz_bar) {
+    HIP_TRY(hipMalloc(&p->fz_bar, 4 * sizeof(unsigned)));
+    HIP_TRY(hipMemsetAsync(p->fz_bar, 0, 4 * sizeof(unsigned), p->stream));
+    HIP_TRY(hipMalloc(&p->fz_part, (size_t)2 * G * 4 * sizeof(double)));
+  }
+  if (iters + 1 > p->fz_beta_cap) {
+    if (p->fz_beta) (void)hipFree(p->fz_beta);
+    p->fz_beta = nullptr; p->fz_beta_cap = 0;
+    HIP_TRY(hipMalloc(&p->fz_beta, (size_t)(iters + 1) * sizeof(double)));
+    p->fz_beta_cap = iters + 1;
+  }
+  if (!f->y_valid) {
+    hipLaunchKernelGGL(fos::form_y_kernel, dim3(grid_1d(p->n, 256, 256)), dim3(256), 0, p->stream, f->x_cur, f->x_prev, f->h_beta,
+                       f->ynext, p->n);
+    LAUNCH_CHECK();
+    f->y_valid = true;
+  }
+  // the momentum sequence of a plain run does not depend on the data: beta[k] for y_k, beta[k + 1] ... beta[iters]
+  std::vector<double> betas((size_t)iters + 1);
+  betas[0] = f->h_beta;
+  const long long k0 = f->h_k;
+  for (int k = 0; k < iters; ++k) {
+    host_momentum(f->prm, f->h_k, &f->h_t, &f->h_beta);
+    betas[(size_t)k + 1] = f->h_beta;
+    f->h_k += 1;
+  }
+  HIP_TRY(hipMemcpyAsync(p->fz_beta, betas.data(), betas.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));          // (the host vector must outlive the copy)
+  fos::FusedArgs a{};
+  a.A = (const float*)p->A; a.lda = p->lda; a.b = p->b; a.m = p->m; a.n = (int)p->n;
+  a.rows_per_wg = ((p->m + G - 1) / G + fos::FZ_ROWS - 1) / fos::FZ_ROWS * fos::FZ_ROWS;
+  a.slabs = p->slabs; a.y = f->ynext; a.x_cur = f->x_cur; a.x_prev = f->x_prev; a.beta = p->fz_beta; a.part = p->fz_part;
+  a.rr_part = p->rr_part; a.bar = p->fz_bar; a.iters = iters; a.prox_kind = f->prm.prox_kind; a.k0 = k0;
+  a.tau = f->prm.tau; a.alpha1 = f->prm.alpha1; a.alpha2 = f->prm.alpha2;
+  a.timeout_ticks = 100000000ull * 2ull;           // 2 s of the 100 MHz wall clock per wait
+  if ((rc = prof_mark(p, true))) return rc;
+  const size_t lds = fos::fz_lds_bytes((int)p->n);
+  switch ((int)(p->n / 2048)) {
+    case 1: rc = launch_fused<1>(a, G, lds, p->stream); break;
+    case 2: rc = launch_fused<2>(a, G, lds, p->stream); break;
+    case 3: rc = launch_fused<3>(a, G, lds, p->stream); break;
+    default: rc = launch_fused<4>(a, G, lds, p->stream); break;
+  }
+  if (rc) return rc;
+  if ((rc = prof_mark(p, false))) return rc;
+  f->pending = false;
+  f->plain_count += iters;
+  const long long last = f->h_k - 1;
+  const double* cur = p->fz_part + (size_t)(last & 1) * G * 4;
+  const double* prev = iters >= 2 ? p->fz_part + (size_t)((last - 1) & 1) * G * 4 : nullptr;
+  hipLaunchKernelGGL(fos::fista_finalize_plain_kernel, dim3(1), dim3(64), 0, p->stream, cur, prev, G, p->rr_part, G, f->scal,
+                     f->h_t, f->h_beta, f->h_k);
+  LAUNCH_CHECK();
+  f->plain_count = 0;                              // part2 of the two-launch path starts afresh
+  // a grid-wide wait that ran out leaves the state invalid: report it (synchronises)
+  unsigned bad = 0;
+  HIP_TRY(hipMemcpyAsync(&bad, p->fz_bar + 2, sizeof(unsigned), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  if (bad) return fail(FOS_ERR_STATE, "fos_fista_run_fused: a grid-wide wait timed out (workgroups not co-resident?); state invalid");
   return FOS_OK;
 }
 

@@ -168,6 +168,12 @@ struct fos_problem {
   int* cp_error = nullptr;
   unsigned cp_epoch = 1;
   int cp_mode = 0;                   // 0: planner's choice, 1: FOS_PLAN_CLUSTER, 2: FOS_PLAN_NO_CLUSTER
+  // fused persistent step (fused_step.hpp, fos_fista_run_fused): barrier words, per-workgroup partials, beta sequence
+  bool fused_on = false;             // FOS_PLAN_FUSED_MFMA: plain fos_fista_run calls take fos_fista_run_fused where served
+  unsigned* fz_bar = nullptr;
+  double* fz_part = nullptr;
+  double* fz_beta = nullptr;
+  int fz_beta_cap = 0;
   // optional kernel timing (fos_problem_profile)
   int profiling = 0;                 // 0 off, N: bracket every N-th launch of the A pass
   int64_t prof_seq = 0;

@@ -869,7 +869,7 @@ int fos_problem_replan(fos_problem* p, unsigned flags) {
   if (!p) return fail(FOS_ERR_ARG, "fos_problem_replan: null");
   if (p->col_sharded) return fail(FOS_ERR_UNSUPPORTED, "fos_problem_replan: a column-sharded problem keeps its two-phase plan");
   if (flags & ~(unsigned)(FOS_PLAN_NO_RESIDENT | FOS_PLAN_NO_TALL | FOS_PLAN_NO_WIDE | FOS_PLAN_NO_COLBLOCK | FOS_PLAN_CLUSTER |
-                           FOS_PLAN_INTERLEAVE | FOS_PLAN_NO_INTERLEAVE | FOS_PLAN_NO_CLUSTER))
+                           FOS_PLAN_INTERLEAVE | FOS_PLAN_NO_INTERLEAVE | FOS_PLAN_NO_CLUSTER | FOS_PLAN_FUSED_MFMA))
     return fail(FOS_ERR_ARG, "fos_problem_replan: unknown flag");
   // the multi-lambda workspace follows its own plan (one-read cluster form or two products): rebuilt on first use
   {
@@ -879,7 +879,8 @@ int fos_problem_replan(fos_problem* p, unsigned flags) {
     p->rbuf16 = p->slabs16 = p->cp_xchg = nullptr; p->cp_flags = nullptr; p->cp_error = nullptr;
     p->cp_cs = p->cp_clusters = 0;
     p->cp_mode = (flags & FOS_PLAN_CLUSTER) ? 1 : (flags & FOS_PLAN_NO_CLUSTER) ? 2 : 0;
-    flags &= ~(unsigned)(FOS_PLAN_CLUSTER | FOS_PLAN_NO_CLUSTER);
+    p->fused_on = (flags & FOS_PLAN_FUSED_MFMA) != 0;
+    flags &= ~(unsigned)(FOS_PLAN_CLUSTER | FOS_PLAN_NO_CLUSTER | FOS_PLAN_FUSED_MFMA);
   }
   // workspace sized for the old plan (slab stride, fp64 slabs) is dropped and rebuilt
   void* drop[] = {p->slabs, p->rr_part, p->rr2_part, p->slabs_dd, p->rr_dd};
@@ -915,7 +916,7 @@ int fos_problem_destroy(fos_problem* p) {
   if (!p) return FOS_OK;
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   void* bufs[] = {p->slabs, p->rr_part, p->rr2_part, p->rvec, p->gbuf_own, p->ybuf, p->dscal, p->part, p->xp, p->q_part, p->bt_out,
-                  p->slabs_dd, p->rr_dd, p->lhist, p->rbuf16, p->rcols16, p->slabs16, p->rneg, p->zeros, p->cp_xchg, p->cp_flags,
+                  p->slabs_dd, p->rr_dd, p->lhist, p->rbuf16, p->rcols16, p->slabs16, p->rneg, p->zeros, p->cp_xchg, p->cp_flags, p->fz_bar, p->fz_part, p->fz_beta,
                   p->cp_error};
   for (void* q : bufs)
     if (q) (void)hipFree(q);
@@ -933,7 +934,8 @@ int fos_problem_plan(const fos_problem* p, int32_t plan[8]) {
   plan[4] = p->nwg;
   plan[5] = p->nslabs;
   plan[6] = (p->path == 0 ? 1 : 0) | (p->resident ? 2 : 0) | (p->tall ? 4 : 0) | (p->colblock ? 8 : 0) | (p->cp_cs ? 16 : 0) |
-            ((p->il && p->entry && p->entry->with_g_il && p->path == 0 && !p->colblock && !p->tall) ? 32 : 0);
+            ((p->il && p->entry && p->entry->with_g_il && p->path == 0 && !p->colblock && !p->tall) ? 32 : 0) |
+            (p->fused_on ? 64 : 0);
   plan[7] = p->ncu;
   return FOS_OK;
 }

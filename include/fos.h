@@ -38,8 +38,11 @@ enum { FOS_PLAN_NO_RESIDENT = 1, FOS_PLAN_NO_TALL = 2, FOS_PLAN_NO_WIDE = 4, FOS
        FOS_PLAN_INTERLEAVE = 32,  /* rows of the streaming pass dealt round-robin to the workgroups (all CUs read one
                                      contiguous window) instead of one contiguous block per workgroup ...           */
        FOS_PLAN_NO_INTERLEAVE = 64, /* ... or never; neither bit: the planner's default for the shape */
-       FOS_PLAN_NO_CLUSTER = 128    /* never the one-read cluster form (neither cluster bit: the planner takes it where it
-                                       measured ahead - fp32, exactly 4096 or 8192 columns, >= 2 GiB, unsharded) */ };
+       FOS_PLAN_NO_CLUSTER = 128,   /* never the one-read cluster form (neither cluster bit: the planner takes it where it
+                                       measured ahead - fp32, exactly 4096 or 8192 columns, >= 2 GiB, unsharded) */
+       FOS_PLAN_FUSED_MFMA = 256    /* OPT IN: plain fos_fista_run calls take the one-launch persistent step of
+                                       fos_fista_run_fused (LDS-staged panels, row dots on the matrix cores, resident
+                                       iterate) wherever the shape is served */ };
 
 typedef struct fos_problem fos_problem;   /* A, b, launch plan, workspace            */
 typedef struct fos_comm fos_comm;         /* communicator of a row-sharded problem   */
@@ -95,7 +98,7 @@ int fos_problem_set_stream(fos_problem* p, void* stream);
  *               single pass is the row-per-thread kernel, which has no alignment requirements; bit 3: rows wider than
  *               any single-pass kernel - column blocks through the streaming kernel in two phases, A read twice;
  *               bit 4: set once fos_fista_run_multi has planned the one-read cluster form of the matrix-core pass;
- *               bit 5: the streaming pass deals its rows round-robin to the workgroups), CUs} */
+ *               bit 5: the streaming pass deals its rows round-robin to the workgroups; bit 6: FOS_PLAN_FUSED_MFMA), CUs} */
 int fos_problem_plan(const fos_problem* p, int32_t plan[8]);
 /* Re-run the planner with kernel families switched off (FOS_PLAN_* bits): NO_RESIDENT keeps small problems off the
  * one-launch LDS-resident loop, NO_TALL keeps n <= 64 off the row-per-thread pass, NO_WIDE keeps 16384 < n <= 32768 off
@@ -254,6 +257,14 @@ int fos_fista_run_history(fos_fista* f, int iters, double* x_hist, double* hist,
  * caller then runs the handles one by one.
  * SURVEY.md 8(f) rank 3. */
 int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters);
+/* BASELINE north_star's literal step, opt-in: `iters` plain iterations in ONE persistent launch - A staged through LDS
+ * in 4-row panels, the row dots A y on v_mfma_f32_4x4x1_16B_f32, A^T r on the VALU from the staged tile, a grid-wide
+ * barrier, then prox + momentum by the workgroup that OWNS the columns, whose slice of x_k, x_{k-1} stays in its LDS for
+ * the whole run (csrc/fused_step.hpp; iterative_solvers.py:170-242, :289-342).  Same iterates as fos_fista_run to 1e-6.
+ * fp32 A with 2048 / 4096 / 6144 / 8192 columns, aligned rows, m >= 8 x CUs, unsharded, plain runs (FOS_ERR_UNSUPPORTED
+ * otherwise).  Synchronises at the end (reports a timed-out grid-wide wait as FOS_ERR_STATE).  The default two-launch step
+ * measures faster: this entry point exists so that the comparison is a measurement. */
+int fos_fista_run_fused(fos_fista* f, int iters);
 /* Split form for host-driven control (grad-norm stop :179, backtracking :183-197, sharded runs):
  *   fos_fista_grad    gbuf[0..n) = A^T (A y_k - b) (WITHOUT alpha2*y), gbuf[n] = ||A y_k - b||^2 (float)
  *   fos_fista_update  prox + momentum from gbuf (after an optional all-reduce of gbuf[0..n]) */

@@ -1056,6 +1056,61 @@ def test_fista_path_lockstep_with_restart_and_ratio_stop(fos, kind, m, n, nlam):
             assert len(stops) > 1 or min(stops) < 60, "the case must exercise a stop"
 
 
+@pytest.mark.parametrize("m,n", [(3000, 2048), (2100, 4096), (2561, 6144), (4099, 8192)])
+def test_fused_persistent_mfma_step(fos, m, n):
+    """BASELINE north_star's literal step, opt-in (fos_fista_run_fused / FOS_PLAN_FUSED_MFMA): ONE persistent launch per run,
+    A staged through LDS in 4-row panels, the row dots on v_mfma_f32_4x4x1_16B_f32, prox + momentum by the workgroup that
+    owns the columns, the iterate resident in LDS.  Against the oracle (1e-5) and the default two-launch step (1e-6) for
+    FISTA (lasso, l2 in the smooth part), FISTA-delta and the fused ISTA with the elastic-net prox; the state carries over
+    between fused calls and between the two forms; ragged row counts (partial last panel); unsupported shapes refuse."""
+    from fastoptsolver_amd import _core
+    A, b, _ = _data.synth(m, n, 5 + n)
+    At = torch.as_tensor(A.astype(np.float32)).cuda()
+    A = At.to(torch.float64).cpu().numpy()
+    b = b.astype(np.float32).astype(np.float64)
+    prob = fos.prepare(At, b.astype(np.float32))
+    lam = float(np.max(np.abs(A.T @ b)))
+    L = float(np.linalg.norm(A, "fro") ** 2)
+    cases = [dict(mode=_core._lib.MODE_FISTA, a1=0.1 * lam, a2=0.0, kind=_core._lib.PROX_L1),
+             dict(mode=_core._lib.MODE_FISTA, a1=0.05 * lam, a2=0.7, kind=_core._lib.PROX_L1),
+             dict(mode=_core._lib.MODE_DELTA, a1=0.1 * lam, a2=0.0, kind=_core._lib.PROX_L1, delta=3.0),
+             dict(mode=_core._lib.MODE_ISTA, a1=0.1 * lam, a2=0.4, kind=_core._lib.PROX_ENET)]
+    for c in cases:
+        a1, a2 = c["a1"], c["a2"]
+        tau = 1.0 / (L + (a2 if c["kind"] == _core._lib.PROX_L1 and a2 > 0 else 0.0))
+        kw = dict(mode=c["mode"], prox_kind=c["kind"], delta=c.get("delta", 0.0))
+        ref = _core.Fista(prob); ref.reset(tau, a1, a2, **kw); ref.run(22)
+        fz = _core.Fista(prob); fz.reset(tau, a1, a2, **kw)
+        assert fz.run_fused(7) and fz.run_fused(9)                    # the state carries over between fused calls ...
+        fz.run(3)                                                     # ... to the two-launch form ...
+        assert fz.run_fused(3)                                        # ... and back
+        xf, xr = _np(fz.x_tensor()), _np(ref.x_tensor())
+        assert _data.rel(xf, xr) < 1e-6, (c, _data.rel(xf, xr))
+        sf, sr = fz.status(), ref.status()
+        assert int(sf.k) == int(sr.k) == 22 and sf.this_step == pytest.approx(sr.this_step, rel=1e-4)
+        if c["mode"] == _core._lib.MODE_FISTA:
+            x_o = orc.fista(A, b, "elasticnet", a1, a2, max_iter=22, L=L)
+        elif c["mode"] == _core._lib.MODE_DELTA:
+            x_o = orc.fista_delta(A, b, "lasso", a1, 0.0, 3.0, max_iter=22, L=L)
+        else:
+            from oracle.fos_oracle import prox_elastic_net
+            A_, b_ = A, b
+            x_o = orc.ista(np.zeros(n), lambda x: 0.5 * float(np.sum((A_ @ x - b_) ** 2)), lambda x: A_.T @ (A_ @ x - b_),
+                           lambda v, t: prox_elastic_net(v, t, a1, a2), L, max_iter=22)
+        assert _data.rel(xf, x_o) < TOL, c
+    # the plan flag routes the public front-end through it
+    prob.replan(fused_mfma=True)
+    assert prob.plan()["fused_mfma"] == 1
+    x_pub = fos.fista(prob, None, "lasso", 0.1 * lam, 0.0, max_iter=30, L=L)
+    assert _data.rel(_np(x_pub), orc.fista(A, b, "lasso", 0.1 * lam, 0.0, max_iter=30, L=L)) < TOL
+    # shapes / configurations it does not serve refuse (the caller keeps the default step)
+    small = fos.prepare(At[:512], b[:512].astype(np.float32))
+    st = _core.Fista(small); st.reset(1.0 / L, 0.1 * lam, 0.0)
+    assert st.run_fused(3) is False
+    st = _core.Fista(prob); st.reset(1.0 / L, 0.1 * lam, 0.0, adaptive_restart=True)
+    assert st.run_fused(3) is False
+
+
 @pytest.mark.parametrize("m,n,nlam", [(4133, 8188, 16), (2100, 16384, 11), (8200, 4096, 16), (4200, 5000, 6)])
 def test_fista_path_one_read_cluster_pass(fos, m, n, nlam):
     """The opt-in one-read form of the matrix-core pass (cluster_pass.hpp: clusters of 4 / 8 / 16 workgroups share row panels,
