@@ -745,7 +745,8 @@ int ensure_dd(fos_problem* p) {
   return FOS_OK;
 }
 
-// One launch of the one-read multi-lambda pass (cluster_pass.hpp); cooperative: all members of a cluster must be resident.
+// One launch of the one-read multi-lambda pass (cluster_pass.hpp): all members of a cluster must be resident (they are:
+// one workgroup per CU).
 template <int CS>
 int launch_cluster_pass_cs(fos_problem* p) {
   auto kern = fos::cluster_pass_kernel<CS>;
@@ -757,10 +758,12 @@ int launch_cluster_pass_cs(fos_problem* p) {
   const float* b = p->b;
   const float* xp = p->xp;
   unsigned epoch = p->cp_epoch;
-  void* args[] = {&A, &lda, &b, &m, &n, &n_pad, &xp, &rpc, &xcd_aware, &p->cp_xchg, &p->cp_flags, &epoch, &p->slabs16, &n_stride,
-                  &p->cp_error};
-  HIP_TRY(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kern), dim3((unsigned)(p->cp_clusters * CS)),
-                                     dim3(fos::CP_THREADS), args, (unsigned)fos::CP_LDS_BYTES, p->stream));
+  // A PLAIN launch: #CUs workgroups with > 80 KiB of LDS each are co-resident by grid size - all a cooperative launch
+  // would check (MI355X_MICROARCH.md "coop-launch") - every wait in the kernel is bounded, and a process that used
+  // hipLaunchCooperativeKernel dies in rocprofv3's exit handler (tools/exit_probe.py, round 3).
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p->cp_clusters * CS)), dim3(fos::CP_THREADS), (unsigned)fos::CP_LDS_BYTES, p->stream, A,
+                     lda, b, m, n, n_pad, xp, rpc, xcd_aware, p->cp_xchg, p->cp_flags, epoch, p->slabs16, n_stride, p->cp_error);
+  LAUNCH_CHECK();
   p->cp_epoch += (unsigned)(rpc / fos::CP_ROWS) + 16u;
   return FOS_OK;
 }
