@@ -374,18 +374,11 @@ def mfma_reference(device):
            "bf16": dict(line_search_mfma_util=0.115, path_mfma_util=(0.127, 0.124),
                         instruction="v_mfma_f32_16x16x32_bf16 (candidates / residuals as three bf16 terms)",
                         source="profiles/r01_linesearch_mfma.md, profiles/r02_multilambda.md")}
-    # Under rocprofv3 a process that used hipLaunchCooperativeKernel (the one-read cluster pass the planner picks at this
-    # shape) dies with SIGSEGV in the profiler's exit handler AFTER all output is written (tools/exit_probe.py, round 3: the
-    # plain, two-product, L-BFGS and mesh paths exit cleanly, the cluster pass does not).  So that a profiled bench still
-    # ends with exit code 0, this leg keeps to the two-product form when a profiler is attached, and says so.
-    profiled = any(k.startswith("ROCPROF") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
     out = {}
     for kind in ("f32", "bf16"):
         A = A32 if kind == "f32" else A32.to(torch.bfloat16)
         esz = 4 if kind == "f32" else 2
         prob = fos.prepare(A, b)
-        if profiled:
-            prob.replan(cluster=False)
         leg = {}
         # (1) 16 candidates per pass: ||A dlt_j||^2, j < 16, from one read of A
         X = torch.randn(n, 16, device=device)
@@ -432,8 +425,6 @@ def mfma_reference(device):
     del A32, b
     torch.cuda.empty_cache()
     out["workload"] = f"cfg2 shape ({m}x{n}), 1 GPU; kernel_us by HIP events on the launch stream (fos_problem_profile)"
-    if profiled:
-        out["note"] = "profiler attached: the 16-weight leg ran the two-product form (FOS_PLAN_NO_CLUSTER), see bench.py"
     return out
 
 
