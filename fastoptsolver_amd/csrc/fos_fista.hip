@@ -150,6 +150,19 @@ __global__ __launch_bounds__(64) void fold4_kernel(const double* __restrict__ pa
     for (int j = 0; j < 4; ++j) out4[j] = s[j];
 }
 
+// Column-sharded lockstep: the step partials of every weight folded to [weight][4] (re-derived every iteration - the
+// in-place all-reduce behind it must never see its own result, stopped weights included).
+__global__ __launch_bounds__(64) void fold4_multi_kernel(fos::MultiControl mc, int nparts, double* __restrict__ out) {
+  const int v = blockIdx.x;
+  const double* part = mc.part[v];
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < nparts; i += 64)
+    for (int j = 0; j < 4; ++j) s[j] += part[i * 4 + j];
+  for (int j = 0; j < 4; ++j) s[j] = fos::wave_sum(s[j]);
+  if (threadIdx.x == 0)
+    for (int j = 0; j < 4; ++j) out[v * 4 + j] = s[j];
+}
+
 static int launch_finalize(fos_fista* f, int n_rr, double* hist_row = nullptr) {
   fos_problem* p = f->p;
   const double* part = p->part;
@@ -569,12 +582,21 @@ static int run_multi_mfma(fos_fista* const* fs, int nv, int iters, bool controll
       HIP_TRY(hipMemsetAsync(p->cp_error, 0, sizeof(int), p->stream));
     }
   }
+  const bool cols = p->col_sharded;
+  if (cols && !controlled) return fail(FOS_ERR_STATE, "run_multi_mfma: a column-sharded lockstep is device-controlled");
+  if (cols && !p->mfold) HIP_TRY(hipMalloc(&p->mfold, (size_t)fos::BT_NV * 4 * sizeof(double)));
   if (!p->rbuf16) {
     // Panel: product 1 gives a workgroup 64-128 whole rows, so it needs >= 128 * CUs * 2 rows to fill the chip; row
     // splits of product 2: enough (strip, split) workgroups for two per CU.  (A panel that fits the Infinity Cache
     // - ~3000 rows at n = 8192 - would need a split-K product 1; see DESIGN.md "Multi-lambda".)
     const int64_t rows = 256 * (int64_t)p->ncu;
     p->panel_rows = std::min<int64_t>(rows, (p->m + 255) / 256 * 256);
+    if (cols && p->comm->kind != 0) {          // mesh transport: a panel's 16 residual columns are one message
+      const int64_t fit = (int64_t)(p->comm->cap_bytes / (fos::BT_NV * sizeof(float))) / 256 * 256;
+      if (fit < 256) return fail(FOS_ERR_ARG, "fos_fista_run_multi: the communicator's inbox rows hold less than one 256-row "
+                                              "panel of 16 residual columns (16 KiB)");
+      p->panel_rows = std::min<int64_t>(p->panel_rows, fit);
+    }
     const int64_t strips = (p->n + (is_bf16 ? fos::GQ_COLS : fos::GB_COLS) - 1) / (is_bf16 ? fos::GQ_COLS : fos::GB_COLS);
     int64_t splits = std::max<int64_t>(1, (2 * (int64_t)p->ncu + strips - 1) / strips);
     splits = std::min<int64_t>(splits, std::max<int64_t>(1, p->panel_rows / 256));
@@ -642,7 +664,10 @@ static int run_multi_mfma(fos_fista* const* fs, int nv, int iters, bool controll
       const int64_t rows = std::min<int64_t>(p->panel_rows, p->m - row0);
       const char* Ap = reinterpret_cast<const char*>(p->A) + (size_t)row0 * p->lda * esz;
       int nwg1 = 0;
-      if ((rc = launch_batch_product(p, Ap, p->b ? p->b + row0 : nullptr, rows, 1, p->rbuf16, &nwg1))) return rc;
+      // column-sharded: b enters the sum over the ranks once (rank 0); R = sum_p A_p Y_p - b is the ONE exchange per panel
+      const float* bp = (p->b && !(cols && p->comm->rank != 0)) ? p->b + row0 : nullptr;
+      if ((rc = launch_batch_product(p, Ap, bp, rows, 1, p->rbuf16, &nwg1))) return rc;
+      if (cols && (rc = reduce_across(p, p->rbuf16, (size_t)rows * fos::BT_NV, false))) return rc;
       const dim3 grid((unsigned)strips, (unsigned)p->gram_splits);
 #define FOS_GRAM(T, ACC)                                                                                                  \
   hipLaunchKernelGGL((fos::gram_batch_mfma_kernel<T, ACC>), grid, dim3(fos::GB_THREADS), 0, p->stream, (const T*)Ap, p->lda, \
@@ -660,7 +685,8 @@ static int run_multi_mfma(fos_fista* const* fs, int nv, int iters, bool controll
     }
     if ((rc = prof_mark(p, false))) return rc;
     // row-sharded problem: the 16 partial gradients (all row splits) are summed over the ranks before the updates
-    if ((rc = reduce_across(p, p->slabs16, (size_t)p->gram_splits * fos::BT_NV * p->n, false))) return rc;
+    // (column-sharded: the gradient block is local)
+    if (!cols && (rc = reduce_across(p, p->slabs16, (size_t)p->gram_splits * fos::BT_NV * p->n, false))) return rc;
     if (controlled) {                            // update (device beta) -> bookkeeping of all weights -> their y_{k+1}
       fos::MultiUpdate mu{};
       for (int v = 0; v < nv; ++v) {
@@ -671,7 +697,15 @@ static int run_multi_mfma(fos_fista* const* fs, int nv, int iters, bool controll
       hipLaunchKernelGGL(fos::fista_update_multi_kernel, dim3(fs[0]->nupd, nv), dim3(256), 0, p->stream, p->slabs16,
                          p->gram_splits, (int)p->n, mu, fs[0]->prm, p->xp, is_bf16 ? fos::YOUT_XQ : fos::YOUT_XP, 0);
       LAUNCH_CHECK();
-      hipLaunchKernelGGL(fos::fista_finalize_multi_kernel, dim3(nv), dim3(64), 0, p->stream, mc, fs[0]->nupd, fs[0]->prm);
+      if (cols) {                                // step norms, ||x||^2, ||x||_1 are sums over the column blocks of all ranks
+        hipLaunchKernelGGL(fold4_multi_kernel, dim3(nv), dim3(64), 0, p->stream, mc, fs[0]->nupd, p->mfold);
+        LAUNCH_CHECK();
+        if ((rc = reduce_across(p, p->mfold, (size_t)nv * 4, true))) return rc;
+        fos::MultiControl mf = mc;
+        for (int v = 0; v < nv; ++v) mf.part[v] = p->mfold + (size_t)v * 4;
+        hipLaunchKernelGGL(fos::fista_finalize_multi_kernel, dim3(nv), dim3(64), 0, p->stream, mf, 1, fs[0]->prm);
+      } else
+        hipLaunchKernelGGL(fos::fista_finalize_multi_kernel, dim3(nv), dim3(64), 0, p->stream, mc, fs[0]->nupd, fs[0]->prm);
       LAUNCH_CHECK();
       hipLaunchKernelGGL(fos::form_y_multi_kernel, dim3(grid_1d(p->n, 256, 64), nv), dim3(256), 0, p->stream, mc, (int)p->n, p->xp,
                          is_bf16 ? fos::YOUT_XQ : fos::YOUT_XP, 0);
@@ -743,6 +777,15 @@ int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters) {
     same_family = same_family && a.mode == c.mode && a.prox_kind == c.prox_kind && a.delta == c.delta;
   }
   const bool shape_ok = p->path == 0 && !p->tall && !p->colblock && !p->resident && !p->col_sharded;
+  // Column-sharded (very wide A): the two products per panel with ONE exchange of the panel's 16 residual columns between
+  // them; always device-controlled (step norms are sums over the ranks).  The matrix-core kernels tile any width.
+  if (p->col_sharded) {
+    if (!(controllable && same_family))
+      return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_multi: a column-sharded lockstep serves one family without the "
+                                       "gradient-norm rule / fp64 gradient / persisted step");
+    if (iters == 0) return FOS_OK;
+    return run_multi_mfma(fs, nv, iters, true);
+  }
   if (!all_plain && controllable && same_family && shape_ok && p->entry != wide_entry() && (nv >= 3 || p->comm)) {
     if (iters == 0) return FOS_OK;
     return run_multi_mfma(fs, nv, iters, true);

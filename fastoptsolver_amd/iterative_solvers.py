@@ -696,7 +696,7 @@ def fista_delta(A, b, reg_type: str, alpha1: float, alpha2: float, delta: float,
 # Regularisation path (extension)
 # ---------------------------------------------------------------------
 def fista_path(A, b, alphas, t_init_factor: float = 1.0, max_iter: int = 500, *, delta=None, L=None, dtype=None,
-               comm=None, tol: float = 0.0, tol_ratio: float = 0.0, adaptive_restart: bool = False,
+               comm=None, cols=None, tol: float = 0.0, tol_ratio: float = 0.0, adaptive_restart: bool = False,
                restart_threshold: float = 1.0, return_info: bool = False):
     """Solve the same (A, b) for several regularisation weights at once.
 
@@ -711,13 +711,19 @@ def fista_path(A, b, alphas, t_init_factor: float = 1.0, max_iter: int = 500, *,
     momentum restarts and the ratio stop are decided per weight on the device every iteration and a stopped weight
     becomes a masked column of the block (three or more weights, matrix-core pass).  ``tol`` adds the reference's
     gradient-norm rule, which sits before the update: those runs go one by one.  ``return_info=True`` also returns
-    ``[(iterations, stop_code), ...]`` per weight."""
+    ``[(iterations, stop_code), ...]`` per weight.
+    ``cols=(lo, hi, n_total)`` with ``comm=``: COLUMN sharding (A is this rank's columns, b whole, each returned x this
+    rank's block) - the lockstep keeps ONE exchange per row panel, the panel's 16 residual columns between the two
+    products, plus 64 doubles of step norms per iteration."""
     reset_metrics()
     if delta is not None:
         assert delta > 2, "In FISTA-Δ, delta must be > 2 for convergence (course requirement)"
-    prob, _ = _sharded_problem(A, b, dtype, comm, None)      # comm: A, b are this rank's rows (matrix-core pass, one
-    like = prob.like                                         # all-reduce of the 16 gradients per iteration)
-    L_val = estimate_lipschitz(prob) if L is None else float(L)
+    prob, _ = _sharded_problem(A, b, dtype, comm, None, cols)    # comm: A, b are this rank's rows (matrix-core pass, one
+    like = prob.like                                             # all-reduce of the 16 gradients per iteration)
+    if L is not None:
+        L_val = float(L)
+    else:
+        L_val = _lipschitz_cols(prob, comm, cols) if cols is not None else estimate_lipschitz(prob)
     mode = _lib.MODE_FISTA if delta is None else _lib.MODE_DELTA
     handles = []
     for a1, a2 in alphas:
@@ -728,7 +734,7 @@ def fista_path(A, b, alphas, t_init_factor: float = 1.0, max_iter: int = 500, *,
         handles.append(st)
     gtimer = _EventTimer(grad_call_times)
     # up to 4 weights: the multi-vector VALU pass where the shape has one; up to 16: the matrix-core pass
-    width = 4 if len(handles) <= 4 else 16
+    width = 4 if len(handles) <= 4 and cols is None else 16
     for i in range(0, len(handles), width):
         group = handles[i:i + width]
         ev = gtimer.start()

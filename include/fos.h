@@ -153,8 +153,10 @@ int fos_problem_set_comm(fos_problem* p, fos_comm* c);
  * g_p = A_p^T r locally; prox and momentum are separable, so the update is local; the four scalar sums of an iteration
  * (step norms, ||grad||^2, ||x||_1, ||x||^2) are all-reduced (4 doubles) so that restart and the stopping rules decide on
  * global numbers.  A_p is read twice per iteration (before and after the exchange).  fos_fista_run / _grad / _update,
- * fos_gemv_pair, fos_residual_objective work on such a problem; the Armijo trials, the fp64 pass, the multi-lambda pass
- * and the one-launch power iteration do not (FOS_ERR_UNSUPPORTED).  Needs the streaming layout (n_p > 64, 16-byte rows). */
+ * fos_gemv_pair, fos_residual_objective, the batched Armijo trials (fos_fista_run_backtracking), the fp64 pass
+ * (fos_gemv_pair_dd), fos_lbfgs_direction_cols and fos_fista_run_multi work on such a problem; the single-candidate trial
+ * (fos_fista_trial), fos_lbfgs_minimize, fos_problem_replan and the one-launch power iteration do not
+ * (FOS_ERR_UNSUPPORTED).  Needs the streaming layout (n_p > 64, 16-byte rows). */
 int fos_problem_set_comm_cols(fos_problem* p, fos_comm* c);
 
 /* Kernel timing for roofline reports: while enabled (enable = N > 0), every N-th launch of the single-pass kernel
@@ -255,6 +257,10 @@ int fos_fista_run_history(fos_fista* f, int iters, double* x_hist, double* hist,
  * column of the block.  FOS_ERR_UNSUPPORTED when the shape has no such kernel (two-pass path, n <= 64, n > 16384 fp32) or
  * a handle uses the gradient-norm rule (tol_grad: it sits before the update) or a device-held step (backtracking): the
  * caller then runs the handles one by one.
+ * A COLUMN-sharded problem (fos_problem_set_comm_cols) takes the matrix-core pass for any number of weights and any block
+ * width, always device-controlled: per row panel ONE all-reduce of the panel's 16 residual columns between the two
+ * products (rows x 16 floats; on the mesh transport the panel is sized to the communicator's inbox rows, >= 16 KiB), the
+ * gradient blocks stay local, 4 doubles per weight of step norms cross per iteration.
  * SURVEY.md 8(f) rank 3. */
 int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters);
 /* BASELINE north_star's literal step, opt-in: `iters` plain iterations in ONE persistent launch - A staged through LDS

@@ -361,6 +361,10 @@ COL_CASES = [dict(), dict(adaptive_restart=True), dict(tol=0.5), dict(tol_ratio=
              dict(backtracking=True, t_init_factor=2.0), dict(backtracking=True, t_init_factor=1.0, return_history=True)]
 
 
+COL_PATH_WEIGHTS = 6
+COL_PATH_CTL = dict(adaptive_restart=True, tol_ratio=0.9)
+
+
 def _cols_worker(rank, world, port, out_dir):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -407,6 +411,21 @@ def _cols_worker(rank, world, port, out_dir):
     sl = fos.LBFGSSolver("ridge", 0.0, a2).fit(prob, None, comm=comm, cols=(lo, hi, n))
     out["xl"], out["lb_counts"] = sl.x_.cpu().numpy(), np.asarray([sl.nit_, sl.nfev_])
     out["lb_hist"] = np.asarray(sl.history_)
+    # the multi-lambda lockstep column-sharded: per panel ONE exchange of the 16 residual columns between the two products
+    lam = float(np.max(np.abs(A.T @ b)))
+    alphas = [(lam * 0.4 * 0.7 ** i, 0.5 if i % 3 == 1 else 0.0) for i in range(COL_PATH_WEIGHTS)]
+    xs = fos.fista_path(prob, None, alphas, max_iter=25, L=L, comm=comm, cols=(lo, hi, n))
+    out["xpath"] = np.stack([x.cpu().numpy() for x in xs])
+    xs, info = fos.fista_path(prob, None, alphas, max_iter=60, L=L, comm=comm, cols=(lo, hi, n), return_info=True,
+                              **COL_PATH_CTL)
+    out["xpath_ctl"], out["path_info"] = np.stack([x.cpu().numpy() for x in xs]), np.asarray(info)
+    # ... and through a communicator whose inbox rows hold one 512-row panel only (two panels, the second one ragged)
+    small = fd.Comm(dist.group.WORLD, transport="mesh", cap_bytes=40 << 10)
+    prob_s = fos.prepare(Ad, b.astype(np.float32), pad=False)
+    xs = fos.fista_path(prob_s, None, alphas[:3], max_iter=25, L=L, comm=small, cols=(lo, hi, n))
+    out["xpath_small"] = np.stack([x.cpu().numpy() for x in xs])
+    small.check()
+    del prob_s
     refused = 0
     for call in (lambda: prob.replan(no_colblock=True), lambda: prob.power_iter(np.ones(hi - lo, np.float32), 3)):
         try:
@@ -425,7 +444,8 @@ def test_column_sharding_two_processes(tmp_path):
     """A split by COLUMNS over two ranks (each: all rows, half the columns, the whole b): the concatenated blocks of x
     equal the unsharded oracle for the plain loop, adaptive restart, the three stopping rules (same stopping iteration),
     the history objective, backtracking (round 3: 16 candidates' m-vectors in one all-reduce; same shrink counts),
-    FISTA-delta, the fp64 `fg` pass, and with L from the column-sharded power iteration."""
+    FISTA-delta, the fp64 `fg` pass, L-BFGS, the multi-lambda lockstep (plain, device-controlled, two panels), and with L
+    from the column-sharded power iteration."""
     import torch.multiprocessing as mp
     world = 2
     mp.spawn(_cols_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
@@ -464,3 +484,21 @@ def test_column_sharding_two_processes(tmp_path):
             assert np.allclose(r[0][f"obj{i}"], h_ref["obj"], rtol=TOL), kw
             assert _data.rel(cat(f"xmid{i}"), h_ref["x"][len(h_ref["x"]) // 2]) < TOL, kw
     assert _data.rel(cat("xd"), orc.fista_delta(A, b, "lasso", a1, 0.0, 3.0, max_iter=30, L=L)) < TOL
+    # the lockstep over the column blocks: every weight equals its own unsharded oracle run - plain, with restart and the
+    # ratio stop decided per weight (same stopping iteration on both ranks), and through the two-panel communicator
+    lam = float(np.max(np.abs(A.T @ b)))
+    alphas = [(lam * 0.4 * 0.7 ** i, 0.5 if i % 3 == 1 else 0.0) for i in range(COL_PATH_WEIGHTS)]
+    assert np.array_equal(r[0]["path_info"], r[1]["path_info"])
+    stops = 0
+    for j, (p1, p2) in enumerate(alphas):
+        x_ref = orc.fista(A, b, "elasticnet", p1, p2, max_iter=25, L=L)
+        got = np.concatenate([r[k]["xpath"][j] for k in range(world)])
+        assert _data.rel(got, x_ref) < TOL, j
+        if j < 3:
+            assert _data.rel(np.concatenate([r[k]["xpath_small"][j] for k in range(world)]), x_ref) < TOL, j
+        x_ref, h_ref = orc.fista(A, b, "elasticnet", p1, p2, max_iter=60, L=L, return_history=True, **COL_PATH_CTL)
+        got = np.concatenate([r[k]["xpath_ctl"][j] for k in range(world)])
+        assert _data.rel(got, x_ref) < TOL, j
+        assert int(r[0]["path_info"][j][0]) == len(h_ref["obj"]), (j, r[0]["path_info"][j], len(h_ref["obj"]))
+        stops += int(r[0]["path_info"][j][1] != 0)
+    assert stops >= 1                                       # the case exercises a masked column
