@@ -296,6 +296,10 @@ def run_workload(name, args, rank, world, device, steps, warmup, want_cpu, dist,
     elapsed = float(np.median(runs))
     k_ms, k_launches = eng.prob.profile_read()
     eng.prob.profile(0)
+    # beside the nominal 8 TB/s, what THIS box delivers to a kernel that only loads (the same A, after the timed
+    # regions): fos_stream_read_probe, 8 non-temporal 16-byte loads in flight per thread, HIP events around the launches.
+    from fastoptsolver_amd import _core
+    read_gbps, read_us = _core.stream_read_probe(A, launches=max(4, min(40, int(2e11 // max(A.numel() * A.element_size(), 1)))))
     st = eng.status()
     assert int(st.k) == warmup + steps * repeats and st.stopped == 0, (int(st.k), st.stopped)
     assert math.isfinite(st.this_step) and st.this_step > 0.0, "iterate did not move: invalid run"
@@ -319,6 +323,7 @@ def run_workload(name, args, rank, world, device, steps, warmup, want_cpu, dist,
         kernel_us=kern_us, kernel_launches=int(k_launches), bytes_iter_per_gpu=b_iter,
         achieved_gbps=b_iter / (kern_us * 1e-6) / 1e9 if k_launches else None,
         step_gbps=b_iter / (elapsed / steps) / 1e9, lipschitz_s=lip_s, L=L, alpha1=a1, alpha2=a2,
+        read_gbps=read_gbps, read_us=read_us,
         plan=eng.prob.plan(), m=m, n=n, rows_per_gpu=hi - lo, dtype=cfg["dtype"], reg=cfg["reg"],
         final_step_norm=st.this_step, replicas_identical=replicas_identical)
     cpu, parity = None, None
@@ -504,6 +509,10 @@ def roofline_obj(res, traffic_key):
         "kernel_launches_timed": res["kernel_launches"],
         "algorithmic_bytes_per_launch": res["bytes_iter_per_gpu"],
         "whole_step_frac": res["step_gbps"] / HBM_PEAK_GBPS,
+        # context, not the denominator of `frac`: a read-only pass over the same A on this box, this run
+        "stream_read_measured": {"gbps": res["read_gbps"], "us_per_pass_over_A": res["read_us"],
+                                 "kernel_over_stream_read": (res["achieved_gbps"] or 0.0) / res["read_gbps"],
+                                 "what": "fos_stream_read_probe: loads + adds only, same buffer, HIP events"},
     }
 
 

@@ -465,6 +465,19 @@ class Fista:
         return self.prob.vec_out(out)
 
 
+def stream_read_probe(t, launches=20):
+    """(GB/s, microseconds per pass) of a read-only pass over the contiguous CUDA tensor `t` (fos_stream_read_probe): the
+    box's own streaming-read figure that bench.py reports beside the nominal peak.  Synchronises."""
+    if not (t.is_cuda and t.is_contiguous()):
+        raise ValueError("stream_read_probe: contiguous device tensor expected")
+    nbytes = t.numel() * t.element_size() // 16 * 16
+    gbps, us = C.c_double(), C.c_double()
+    with torch.cuda.device(t.device):
+        _lib.check(_lib.load().fos_stream_read_probe(ptr(t), nbytes, int(launches), torch.cuda.current_stream().cuda_stream,
+                                                    C.byref(gbps), C.byref(us)), "fos_stream_read_probe")
+    return gbps.value, us.value
+
+
 def run_multi(handles, iters):
     """Advance up to 16 Fista handles of one Problem in lockstep (fos_fista_run_multi).
     Returns False when this shape / configuration has no multi-vector kernel (callers then run them one by one)."""

@@ -896,6 +896,64 @@ int fos_problem_replan(fos_problem* p, unsigned flags) {
   return ensure_workspace(p);
 }
 
+// Read-only streaming probe: what this box's HBM delivers to a kernel that does nothing but load (the context figure SURVEY.md
+// 8d asks for beside the nominal 8 TB/s).  Every thread keeps 8 independent 16-byte non-temporal loads in flight; consecutive
+// waves read consecutive KiB; the sums keep the loads alive.
+__global__ __launch_bounds__(512) void stream_read_kernel(const fos::f32x4* __restrict__ src, size_t n16, float* __restrict__ sink) {
+  constexpr int UNR = 8;
+  const size_t stride = (size_t)gridDim.x * 512;
+  size_t i = (size_t)blockIdx.x * 512 + threadIdx.x;
+  fos::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (; i + (UNR - 1) * stride < n16; i += UNR * stride) {
+    fos::f32x4 v[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) acc += v[u];
+  }
+  for (; i < n16; i += stride) {
+    acc += __builtin_nontemporal_load(src + i);
+  }
+  const float t = fos::wave_sum((acc.x + acc.y) + (acc.z + acc.w));
+  if ((threadIdx.x & 63) == 0) sink[blockIdx.x * 8 + (threadIdx.x >> 6)] = t;
+}
+
+int fos_stream_read_probe(const void* buf, size_t bytes, int launches, void* stream, double* gbps_out, double* us_out) {
+  if (!buf || bytes < 16 || (bytes & 15) || (reinterpret_cast<uintptr_t>(buf) & 15) || launches < 1 || !gbps_out)
+    return fail(FOS_ERR_ARG, "fos_stream_read_probe: needs a 16-byte aligned buffer of a multiple of 16 bytes and launches >= 1");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int dev = 0, ncu = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+  const size_t n16 = bytes / 16;
+  const int grid = (int)std::max<size_t>(1, std::min<size_t>((size_t)ncu * 4, (n16 + 511) / 512));
+  float* sink = nullptr;
+  HIP_TRY(hipMalloc(&sink, (size_t)grid * 8 * sizeof(float)));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(stream_read_kernel, dim3(grid), dim3(512), 0, st, (const fos::f32x4*)buf, n16, sink);      // warm-up
+    e = hipEventRecord(e0, st);
+    for (int i = 0; i < launches && e == hipSuccess; ++i) {
+      hipLaunchKernelGGL(stream_read_kernel, dim3(grid), dim3(512), 0, st, (const fos::f32x4*)buf, n16, sink);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(e1, st);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+  }
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(sink);
+  if (e != hipSuccess) return fail(FOS_ERR_HIP, std::string("fos_stream_read_probe: ") + hipGetErrorString(e));
+  const double us = (double)ms * 1e3 / launches;
+  *gbps_out = (double)bytes / (us * 1e-6) / 1e9;
+  if (us_out) *us_out = us;
+  return FOS_OK;
+}
+
 int fos_problem_profile(fos_problem* p, int enable) {
   if (!p) return fail(FOS_ERR_ARG, "fos_problem_profile: null");
   p->profiling = enable > 0 ? enable : 0;

@@ -167,6 +167,11 @@ int fos_problem_set_comm_cols(fos_problem* p, fos_comm* c);
 int fos_problem_profile(fos_problem* p, int enable);
 int fos_problem_profile_read(fos_problem* p, double* ms_total, int64_t* launches);
 
+/* Measurement aid (bench.py, SURVEY.md 8d "the box's measured stream-read bandwidth"): `launches` read-only passes over
+ * `bytes` of device memory (16-byte aligned, a multiple of 16) by a kernel that only loads and sums; returns GB/s (1e9) and
+ * microseconds per pass (us_out may be NULL).  Synchronises.  Not part of the solver path. */
+int fos_stream_read_probe(const void* buf, size_t bytes, int launches, void* stream, double* gbps_out, double* us_out);
+
 /* K2: grad = A^T (A y - b) + alpha2*y ; *rr_out (device double, may be NULL) = ||A y - b||^2.
  * Replaces iterative_solvers.py:54, :173-175, :292-294 and lbfgs.py:46-51.  A is read ONCE. */
 int fos_gemv_pair(fos_problem* p, const float* y, float alpha2, float* grad, double* rr_out);

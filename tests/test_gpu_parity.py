@@ -1473,3 +1473,15 @@ def test_fused_ista_log_is_recorded_on_the_device(fos):
         # delta = ||x_new - x||: each iterate carries the fp32 pass's ~1e-7 of ||x||, so small deltas agree absolutely
         assert np.allclose(log["delta"], log_ref["delta"], rtol=1e-5, atol=2e-6 * float(np.linalg.norm(x_ref))), kw
         assert _data.rel(log["x"][len(log["x"]) // 2], log_ref["x"][len(log_ref["x"]) // 2]) < TOL, kw
+
+
+def test_stream_read_probe(fos):
+    """The measurement aid bench.py reports beside the nominal peak: a loads-only pass; bad arguments are refused."""
+    from fastoptsolver_amd import _core, _lib
+    t = torch.ones(1 << 24, device="cuda")
+    gbps, us = _core.stream_read_probe(t, launches=5)
+    assert gbps > 100.0 and us > 0.0 and abs(gbps - t.numel() * 4 / us / 1e3) < 1e-6 * gbps
+    import ctypes as C
+    g = C.c_double()
+    rc = _lib.load().fos_stream_read_probe(C.c_void_p(t.data_ptr() + 4), 1024, 1, None, C.byref(g), None)
+    assert rc == -1
