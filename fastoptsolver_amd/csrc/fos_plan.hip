@@ -897,23 +897,24 @@ int fos_problem_replan(fos_problem* p, unsigned flags) {
 }
 
 // Read-only streaming probe: what this box's HBM delivers to a kernel that does nothing but load (the context figure SURVEY.md
-// 8d asks for beside the nominal 8 TB/s).  Every thread keeps 8 independent 16-byte non-temporal loads in flight; consecutive
-// waves read consecutive KiB; the sums keep the loads alive.
+// 8d asks for beside the nominal 8 TB/s).  The fastest of 18 x 4 loads-only variants (tools/read_probe_sweep.hip,
+// profiles/r03_read_probe_sweep.txt: 7.19 TB/s; grid-stride order 7.1, temporal loads 6.2, 4 workgroups per CU 6.1): one
+// 512-thread workgroup per CU streams its own contiguous range with 8 independent 16-byte non-temporal loads in flight per
+// thread - the access pattern of the single-pass kernel without its arithmetic.
 __global__ __launch_bounds__(512) void stream_read_kernel(const fos::f32x4* __restrict__ src, size_t n16, float* __restrict__ sink) {
-  constexpr int UNR = 8;
-  const size_t stride = (size_t)gridDim.x * 512;
-  size_t i = (size_t)blockIdx.x * 512 + threadIdx.x;
+  constexpr int UNR = 8, THREADS = 512;
+  const size_t per = ((n16 + gridDim.x - 1) / gridDim.x + THREADS * UNR - 1) / (THREADS * UNR) * (THREADS * UNR);
+  const size_t lo = per * blockIdx.x, hi = lo + per < n16 ? lo + per : n16;
+  size_t i = lo + threadIdx.x;
   fos::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (; i + (UNR - 1) * stride < n16; i += UNR * stride) {
+  for (; i + (size_t)(UNR - 1) * THREADS < hi; i += (size_t)UNR * THREADS) {
     fos::f32x4 v[UNR];
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+    for (int u = 0; u < UNR; ++u) v[u] = __builtin_nontemporal_load(src + i + (size_t)u * THREADS);
 #pragma unroll
     for (int u = 0; u < UNR; ++u) acc += v[u];
   }
-  for (; i < n16; i += stride) {
-    acc += __builtin_nontemporal_load(src + i);
-  }
+  for (; i < hi; i += THREADS) acc += __builtin_nontemporal_load(src + i);
   const float t = fos::wave_sum((acc.x + acc.y) + (acc.z + acc.w));
   if ((threadIdx.x & 63) == 0) sink[blockIdx.x * 8 + (threadIdx.x >> 6)] = t;
 }
@@ -926,7 +927,7 @@ int fos_stream_read_probe(const void* buf, size_t bytes, int launches, void* str
   HIP_TRY(hipGetDevice(&dev));
   HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
   const size_t n16 = bytes / 16;
-  const int grid = (int)std::max<size_t>(1, std::min<size_t>((size_t)ncu * 4, (n16 + 511) / 512));
+  const int grid = (int)std::max<size_t>(1, std::min<size_t>((size_t)ncu, (n16 + 4095) / 4096));
   float* sink = nullptr;
   HIP_TRY(hipMalloc(&sink, (size_t)grid * 8 * sizeof(float)));
   hipEvent_t e0 = nullptr, e1 = nullptr;
