@@ -36,6 +36,33 @@ def to_device_vec(x, device=None):
     return t.to(device=dev, dtype=torch.float32).contiguous()
 
 
+UPLOAD_CHUNK_BYTES = 256 << 20
+
+
+def upload_matrix(src, out):
+    """Host matrix -> the device view `out` (same shape; any float dtype, row- or column-major source).  The reference's
+    callers hand float64 ndarrays: converting on the host first cost 0.44 s for 65536 x 8192 (the 500-iteration solve behind
+    it takes 0.19 s).  Here the bytes cross in the SOURCE dtype and layout, 256 MiB at a time, and the conversion / transposition
+    is the device copy into place - the rounding (to nearest even, via float32 for bf16) is the one the host cast performs."""
+    m, n = src.shape
+    if m == 0 or n == 0:
+        return out
+    esz = src.element_size()
+    if src.dtype == out.dtype and src.is_contiguous() and out.is_contiguous():
+        out.copy_(src)
+    elif src.stride(1) == 1 and src.stride(0) == n:                      # row-major: row blocks
+        step = max(1, UPLOAD_CHUNK_BYTES // (n * esz))
+        for r0 in range(0, m, step):
+            out[r0:r0 + step].copy_(src[r0:r0 + step].to(out.device))
+    elif src.stride(0) == 1 and src.stride(1) == m:                      # column-major (Fortran order): column blocks, whose
+        step = max(1, UPLOAD_CHUNK_BYTES // (m * esz))                   # transposes are contiguous on the host
+        for c0 in range(0, n, step):
+            out[:, c0:c0 + step].copy_(src[:, c0:c0 + step].t().to(out.device).t())
+    else:
+        out.copy_(src.to(out.dtype))
+    return out
+
+
 class Like:
     """What the caller handed in (so results come back as the same kind) without keeping the object alive."""
 
@@ -96,10 +123,16 @@ class Problem:
         if pad and not fused_ok:
             n_dev = (n + gran - 1) // gran * gran
             Ap = torch.zeros(m, n_dev, dtype=tdtype, device=dev)
-            Ap[:, :n].copy_(At)                      # one strided copy (host->device or device->device)
+            if At.is_cuda:
+                Ap[:, :n].copy_(At)                  # one strided device copy
+            else:
+                upload_matrix(At, Ap[:, :n])
             At = Ap
         elif not borrowable:
-            At = At.to(device=dev, dtype=tdtype).contiguous()
+            if At.is_cuda:
+                At = At.to(device=dev, dtype=tdtype).contiguous()
+            else:
+                At = upload_matrix(At, torch.empty(m, n, dtype=tdtype, device=dev))
         self.A = At
         self.m, self.n, self.n_dev = m, n, n_dev
         self.lda = int(At.stride(0)) if self.m > 1 else self.n_dev

@@ -34,3 +34,29 @@ def test_shards_fall_on_generator_blocks():
             for r in range(world):
                 lo, hi = shard_rows(m, world, r)
                 assert lo % bench.BLOCK == 0 and hi % bench.BLOCK == 0
+
+
+def test_upload_matrix_layouts_and_dtypes():
+    """Host logic of the boundary: a host matrix reaches its device view in blocks of the SOURCE dtype / layout and is
+    converted by the copy into place - for every layout the result equals the plain host cast (run here with a CPU view
+    standing in for the device buffer; the GPU twin is tests/test_gpu_parity.py::test_prepare_from_host_arrays)."""
+    import numpy as np
+    import torch
+    from fastoptsolver_amd import _core
+    old = _core.UPLOAD_CHUNK_BYTES
+    _core.UPLOAD_CHUNK_BYTES = 1000              # several ragged blocks
+    try:
+        A = np.random.default_rng(0).standard_normal((37, 29))
+        F = np.asfortranarray(A)
+        srcs = [torch.from_numpy(A), torch.from_numpy(F), torch.from_numpy(A.astype(np.float32)), torch.from_numpy(A)[::2, ::3],
+                torch.from_numpy(F)[:, 3:20], torch.from_numpy(A.astype(np.float16)), torch.from_numpy((A * 10).astype(np.int64))]
+        for src in srcs:
+            for dt in (torch.float32, torch.bfloat16):
+                out = torch.empty(src.shape, dtype=dt)
+                assert _core.upload_matrix(src, out) is out and torch.equal(out, src.to(dt)), (src.stride(), src.dtype, dt)
+                pad = torch.zeros(src.shape[0], src.shape[1] + 3, dtype=dt)
+                _core.upload_matrix(src, pad[:, : src.shape[1]])
+                assert torch.equal(pad[:, : src.shape[1]], src.to(dt)) and float(pad[:, src.shape[1]:].abs().sum()) == 0.0
+        assert _core.upload_matrix(torch.empty(0, 5), torch.empty(0, 5)).shape == (0, 5)
+    finally:
+        _core.UPLOAD_CHUNK_BYTES = old

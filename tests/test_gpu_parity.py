@@ -1485,3 +1485,33 @@ def test_stream_read_probe(fos):
     g = C.c_double()
     rc = _lib.load().fos_stream_read_probe(C.c_void_p(t.data_ptr() + 4), 1024, 1, None, C.byref(g), None)
     assert rc == -1
+
+
+def test_prepare_from_host_arrays(fos):
+    """The boundary handed HOST matrices (the reference's callers pass float64 ndarrays): float64 / float32 / Fortran-ordered
+    / strided sources, fp32 and bf16 storage, with and without column padding - the bound matrix equals the host cast bit
+    for bit, whatever the upload block size, and the solve from ndarrays equals the solve on the prepared problem."""
+    from fastoptsolver_amd import _core
+    A, b, _ = _data.synth(517, 260, 3)
+    F = np.asfortranarray(A)
+    old = _core.UPLOAD_CHUNK_BYTES
+    try:
+        for chunk in (old, 100_000):
+            _core.UPLOAD_CHUNK_BYTES = chunk
+            for src in (A, F, A.astype(np.float32), A[::2, ::2], F[:, 4:204], A[:, :257]):
+                for kind, tdt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+                    for pad in (False, True):
+                        prob = fos.prepare(src, b[: src.shape[0]], dtype=kind, pad=pad)
+                        want = torch.from_numpy(np.ascontiguousarray(src)).to(tdt)
+                        got = prob.A[:, : src.shape[1]].cpu()
+                        assert torch.equal(got, want), (src.shape, src.strides, kind, pad, chunk)
+                        assert prob.n_dev == src.shape[1] or float(prob.A[:, src.shape[1]:].abs().sum()) == 0.0
+    finally:
+        _core.UPLOAD_CHUNK_BYTES = old
+    Ar = A.astype(np.float32).astype(np.float64)            # what the device holds
+    br = b.astype(np.float32).astype(np.float64)
+    L = float(np.linalg.norm(Ar, 2) ** 2)
+    lam = float(np.max(np.abs(Ar.T @ br)))
+    x_nd = fos.fista(F, b, "lasso", 0.1 * lam, 0.0, max_iter=40, L=L)
+    assert isinstance(x_nd, np.ndarray) and x_nd.dtype == np.float64
+    assert _data.rel(x_nd, orc.fista(Ar, br, "lasso", 0.1 * lam, 0.0, max_iter=40, L=L)) < TOL
