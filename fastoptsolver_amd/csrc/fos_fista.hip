@@ -457,6 +457,12 @@ int fos_fista_run(fos_fista* f, int iters) {
 }
 
 // The step in ONE persistent launch with the row dots on the matrix cores and A staged through LDS (fused_step.hpp):
+int fos_problem_set_fused_stamps(fos_problem* p, unsigned long long* stamps) {
+  if (!p) return fail(FOS_ERR_ARG, "fos_problem_set_fused_stamps: null");
+  p->fz_stamps = stamps;
+  return FOS_OK;
+}
+
 // BASELINE north_star's literal design, opt-in (the two-launch VALU step measures faster).  Plain runs only.
 int fos_fista_run_fused(fos_fista* f, int iters) {
   if (!f || iters < 0) return fail(FOS_ERR_ARG, "fos_fista_run_fused: bad argument");
@@ -490,8 +496,8 @@ int fos_fista_run_fused(fos_fista* f, int iters) {
     p->rr_cap = G;
   }
   if (!p->fz_bar) {
-    HIP_TRY(hipMalloc(&p->fz_bar, 4 * sizeof(unsigned)));
-    HIP_TRY(hipMemsetAsync(p->fz_bar, 0, 4 * sizeof(unsigned), p->stream));
+    HIP_TRY(hipMalloc(&p->fz_bar, fos::FZ_BAR_WORDS * sizeof(unsigned)));
+    HIP_TRY(hipMemsetAsync(p->fz_bar, 0, fos::FZ_BAR_WORDS * sizeof(unsigned), p->stream));
     HIP_TRY(hipMalloc(&p->fz_part, (size_t)2 * G * 4 * sizeof(double)));
   }
   if (iters + 1 > p->fz_beta_cap) {
@@ -524,6 +530,7 @@ int fos_fista_run_fused(fos_fista* f, int iters) {
   a.rr_part = p->rr_part; a.bar = p->fz_bar; a.iters = iters; a.prox_kind = f->prm.prox_kind; a.k0 = k0;
   a.tau = f->prm.tau; a.alpha1 = f->prm.alpha1; a.alpha2 = f->prm.alpha2;
   a.timeout_ticks = 100000000ull * 2ull;           // 2 s of the 100 MHz wall clock per wait
+  a.stamps = p->fz_stamps;
   if ((rc = prof_mark(p, true))) return rc;
   const size_t lds = fos::fz_lds_bytes((int)p->n);
   switch ((int)(p->n / 2048)) {
@@ -545,7 +552,7 @@ int fos_fista_run_fused(fos_fista* f, int iters) {
   f->plain_count = 0;                              // part2 of the two-launch path starts afresh
   // a grid-wide wait that ran out leaves the state invalid: report it (synchronises)
   unsigned bad = 0;
-  HIP_TRY(hipMemcpyAsync(&bad, p->fz_bar + 2, sizeof(unsigned), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipMemcpyAsync(&bad, p->fz_bar + fos::FZ_LINE, sizeof(unsigned), hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   if (bad) return fail(FOS_ERR_STATE, "fos_fista_run_fused: a grid-wide wait timed out (workgroups not co-resident?); state invalid");
   return FOS_OK;

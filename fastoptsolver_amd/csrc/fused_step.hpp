@@ -44,32 +44,55 @@ struct FusedArgs {
   const double* beta;      // [iters + 1]: beta[k] forms y_k from (x_k, x_{k-1}); beta[k + 1] the next one
   double* part;            // [2][G][4]: {sum d^2, sum gf^2, sum |x|, sum x^2} of the last two iterations (parity of k)
   double* rr_part;         // [G]: ||A_w y - b_w||^2 of the LAST iteration's pass
-  unsigned* bar;           // [0] arrivals, [1] generation, [2] error (a bounded wait ran out)
+  unsigned* bar;           // FZ_BAR_WORDS words, zeroed once: see fz_grid_barrier
   int iters; int prox_kind; long long k0;
   double tau, alpha1, alpha2;
   unsigned long long timeout_ticks;
-};
+  unsigned long long* stamps;   // nullable, [G][8]: 100 MHz wall clock of the LAST iteration - phase A start / end, behind
+};                              // barrier 1, phase B end, behind barrier 2 (measurement hook: fos_problem_set_fused_stamps)
 
-// Grid-wide barrier for a grid that is co-resident by construction.  Returns false (and raises bar[2]) when the wait ran
-// out - the caller leaves the kernel; every other workgroup then runs out too.
+// Grid-wide barrier for a grid that is co-resident by construction, in two levels (round 3: with one arrival counter and the
+// generation word beside it, 256 workgroups arriving together took 9-20 us to get through - 256 read-modify-writes and 255
+// pollers on ONE line, tools/fused_phases.py).  Workgroup w arrives on the counter of group w % 16 (its own 128-byte line);
+// the last of a group arrives on the root; the last of the root bumps the 16 group generations (a line each), and a
+// workgroup polls its group's only.  Layout in 32-word lines: [0] root counter, [1] error flag, [2 + g] group counters,
+// [18 + g] group generations.  Returns false (and raises the error flag) when a wait ran out - the caller leaves the kernel;
+// every other workgroup then runs out too.
+constexpr int FZ_NG = 16, FZ_LINE = 32, FZ_BAR_WORDS = (2 + 2 * FZ_NG) * FZ_LINE;
 __device__ inline bool fz_grid_barrier(unsigned* bar, unsigned nwg, unsigned& gen, unsigned long long timeout_ticks, int* ok_lds) {
   __syncthreads();                                   // this workgroup's stores are issued ...
   if (threadIdx.x == 0) {
     __threadfence();                                 // ... and released at agent scope
     int ok = 1;
-    const unsigned prev = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev == nwg - 1) {
-      __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned w = blockIdx.x, grp = w % FZ_NG;
+    const unsigned ngroups = nwg < (unsigned)FZ_NG ? nwg : (unsigned)FZ_NG;
+    const unsigned gsize = (nwg - grp + FZ_NG - 1) / FZ_NG;              // workgroups w' < nwg with w' % 16 == grp
+    unsigned* root = bar;
+    unsigned* err = bar + FZ_LINE;
+    unsigned* gcnt = bar + (2 + grp) * FZ_LINE;
+    unsigned* ggen = bar + (2 + FZ_NG + grp) * FZ_LINE;
+    bool releaser = false;
+    if (__hip_atomic_fetch_add(gcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
+      __hip_atomic_store(gcnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (release: the reset above is ordered before whatever lets a workgroup arrive on this group's counter again)
+      if (__hip_atomic_fetch_add(root, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1) {
+        __hip_atomic_store(root, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        releaser = true;
+      }
+    }
+    if (releaser) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");         // one fence, then 16 stores in flight together (a release
+      for (unsigned g = 0; g < ngroups; ++g)                     // per store staggered the groups by 0.5 us each)
+        __hip_atomic_store(bar + (2 + FZ_NG + g) * FZ_LINE, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       const unsigned long long t0 = wall_clock64();
-      while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
-        if (__hip_atomic_load(&bar[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() - t0 > timeout_ticks) {
-          __hip_atomic_store(&bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(ggen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() - t0 > timeout_ticks) {
+          __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ok = 0;
           break;
         }
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(2);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -111,7 +134,8 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void fista_fused_kernel(FusedArgs a)
   const int64_t row_bytes = a.lda * 4;
 
   unsigned gen = 0;
-  if (tid == 0) *ok_lds = (int)__hip_atomic_load(&a.bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0)                                                 // the generation this launch starts from (all groups agree)
+    *ok_lds = (int)__hip_atomic_load(a.bar + (2 + FZ_NG + w % FZ_NG) * FZ_LINE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   gen = (unsigned)*ok_lds;
   __syncthreads();
@@ -136,6 +160,8 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void fista_fused_kernel(FusedArgs a)
 #pragma unroll
     for (int q = 0; q < NQ; ++q) gacc[q][0] = gacc[q][1] = gacc[q][2] = gacc[q][3] = 0.f;
     double rr = 0.0;
+    const bool stamp = a.stamps != nullptr && it == a.iters - 1 && tid == 0;
+    if (stamp) a.stamps[w * 8 + 0] = wall_clock64();
 
     u32x4 pre[FZ_ROWS][NQ];
     float bpre[FZ_ROWS];
@@ -150,7 +176,7 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void fista_fused_kernel(FusedArgs a)
         for (int q = 0; q < NQ; ++q) pre[r][q] = load16<true>(rp + (size_t)q * 1024);
       }
     };
-    if (npanels > 0) issue(0);
+    if (it == 0 && npanels > 0) issue(0);                       // later iterations: issued before the grid barrier below
     for (int64_t panel = 0; panel < npanels; ++panel) {
       // stage the panel: this wave's region of the tile (private to the wave: no workgroup barrier around it)
       float bcur[FZ_ROWS];
@@ -216,13 +242,47 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void fista_fused_kernel(FusedArgs a)
       }
       if (tid == 0 && it == a.iters - 1) a.rr_part[w] = rr;     // (every thread holds the same rr)
     }
+    if (stamp) a.stamps[w * 8 + 1] = wall_clock64();
+    // A does not change: the first panel of the NEXT iteration is requested now and arrives behind the two grid barriers
+    // and phase B (its registers are idle there) - the pass restarts without an HBM round trip
+    if (it + 1 < a.iters && npanels > 0) issue(0);
     if (!fz_grid_barrier(a.bar, G, gen, a.timeout_ticks, ok_lds)) return;
+    if (stamp) a.stamps[w * 8 + 2] = wall_clock64();
 
     // ---- phase B: the owned columns ------------------------------------------------------------------------------------
     if (own_n > 0) {
-      const int c = tid % own, grp = tid / own;                  // 512 / own groups, each summing every (512/own)-th slab
+      const int c = tid % own, grp = tid / own;                  // 512 / own groups
       const int ngrp = FZ_THREADS / own > 16 ? 16 : FZ_THREADS / own;
-      if (grp < ngrp && c < own_n) {
+      if ((own & 3) == 0 && own_n == own) {
+        // The G slab rows of the owned columns, ALL requested at once: a thread takes 4 columns (16 bytes) of every
+        // rows_par-th slab, four independent loads per trip (G = 256, own = 32: 64 rows in parallel, one trip) - the slabs
+        // were written by other XCDs, every load is a trip to the memory side and a dependent chain of them was the
+        // phase's whole cost.  Fixed order: rows -> 16 groups -> column.  The tile is idle here and serves as scratch.
+        const int cg = own >> 2, rows_par = FZ_THREADS / cg;
+        const int c4 = tid % cg, sr = tid / cg;
+        float* scratch = tile;                                   // [rows_par][own] <= 2048 floats
+        if (sr < rows_par) {
+          const float* base = a.slabs + own_lo + 4 * c4;
+          f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+          unsigned sl = (unsigned)sr;
+          const unsigned rp = (unsigned)rows_par;
+          for (; sl + 3 * rp < G; sl += 4 * rp) {
+            const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(base + (int64_t)sl * n);
+            const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(base + (int64_t)(sl + rp) * n);
+            const f32x4_t v2 = *reinterpret_cast<const f32x4_t*>(base + (int64_t)(sl + 2 * rp) * n);
+            const f32x4_t v3 = *reinterpret_cast<const f32x4_t*>(base + (int64_t)(sl + 3 * rp) * n);
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+          }
+          for (; sl < G; sl += rp) s0 += *reinterpret_cast<const f32x4_t*>(base + (int64_t)sl * n);
+          *reinterpret_cast<f32x4_t*>(scratch + sr * own + 4 * c4) = (s0 + s1) + (s2 + s3);
+        }
+        __syncthreads();
+        if (grp < ngrp) {
+          float s = 0.f;
+          for (int r = grp; r < rows_par; r += ngrp) s += scratch[r * own + c];
+          gsum[grp * FZ_OWN_MAX + c] = s;
+        }
+      } else if (grp < ngrp && c < own_n) {
         float s = 0.f;
         for (unsigned sl = (unsigned)grp; sl < G; sl += (unsigned)ngrp) s += a.slabs[(int64_t)sl * n + own_lo + c];
         gsum[grp * FZ_OWN_MAX + c] = s;
@@ -254,7 +314,9 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void fista_fused_kernel(FusedArgs a)
     } else if (tid < 4) {
       a.part[(((a.k0 + it) & 1) * (long long)G + w) * 4 + tid] = 0.0;
     }
+    if (stamp) a.stamps[w * 8 + 3] = wall_clock64();
     if (!fz_grid_barrier(a.bar, G, gen, a.timeout_ticks, ok_lds)) return;
+    if (stamp) a.stamps[w * 8 + 4] = wall_clock64();
   }
   if (tid < own_n) { a.x_cur[own_lo + tid] = xs_cur[tid]; a.x_prev[own_lo + tid] = xs_prev[tid]; }
 }

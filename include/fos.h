@@ -276,6 +276,10 @@ int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters);
  * otherwise).  Synchronises at the end (reports a timed-out grid-wide wait as FOS_ERR_STATE).  The default two-launch step
  * measures faster: this entry point exists so that the comparison is a measurement. */
 int fos_fista_run_fused(fos_fista* f, int iters);
+/* Measurement hook of the persistent step: stamps = device buffer of #CUs x 8 uint64 (NULL = off); every workgroup then
+ * records the 100 MHz wall clock of the LAST iteration of a fos_fista_run_fused call - [0] phase A starts, [1] phase A
+ * ends, [2] behind the first grid barrier, [3] phase B ends, [4] behind the second grid barrier.  The buffer is borrowed. */
+int fos_problem_set_fused_stamps(fos_problem* p, unsigned long long* stamps);
 /* Split form for host-driven control (grad-norm stop :179, backtracking :183-197, sharded runs):
  *   fos_fista_grad    gbuf[0..n) = A^T (A y_k - b) (WITHOUT alpha2*y), gbuf[n] = ||A y_k - b||^2 (float)
  *   fos_fista_update  prox + momentum from gbuf (after an optional all-reduce of gbuf[0..n]) */

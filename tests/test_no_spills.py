@@ -31,7 +31,7 @@ def test_library_kernels_do_not_spill(tmp_path):
     assert len(kernels) > 40, "resource-usage remarks not found"
     # The one exception: the opt-in persistent step at n = 8192 (fused_step.hpp, NQ = 4) keeps y as matrix-instruction
     # operands (64 VGPRs), a panel in flight (64) and its staging addresses live at once and spills a handful of registers
-    # (measured with them: 77 % of the roofline; the default two-launch step is the product path).  Bounded, not waived.
+    # (measured with them: 80 % of the roofline; the default two-launch step is the product path).  Bounded, not waived.
     allowed = {k for k in kernels if "fista_fused_kernelILi4E" in k and kernels[k].get("VGPRs Spill", 0) <= 8}
     bad = {k: v for k, v in kernels.items()
            if (v.get("VGPRs Spill", 0) or v.get("ScratchSize [bytes/lane]", 0)) and k not in allowed}
