@@ -793,16 +793,16 @@ int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters) {
     if (iters == 0) return FOS_OK;
     return run_multi_mfma(fs, nv, iters, true);
   }
-  if (!all_plain && controllable && same_family && shape_ok && p->entry != wide_entry() && (nv >= 3 || p->comm)) {
+  if (!all_plain && controllable && same_family && shape_ok && p->entry != wide_entry(p->dtype) && (nv >= 3 || p->comm)) {
     if (iters == 0) return FOS_OK;
     return run_multi_mfma(fs, nv, iters, true);
   }
   const bool streaming = shape_ok && all_plain;
   // (a sharded problem takes the matrix-core pass for any number of weights: its 16 gradients are one 16 x n all-reduce)
-  MultiLaunch fn = (streaming && !p->comm && p->dtype == FOS_F32 && p->entry != wide_entry()) ? find_multi(p->n, nv) : nullptr;
+  MultiLaunch fn = (streaming && !p->comm && p->dtype == FOS_F32 && p->entry != wide_entry(p->dtype)) ? find_multi(p->n, nv) : nullptr;
   // the two-product pass costs about two single-vector passes per iteration whatever the number of weights: it pays
   // from three weights on (profiles/r02_multilambda.md); two weights without a VALU multi-vector kernel run one by one
-  if (!fn && streaming && p->entry != wide_entry() && (nv >= 3 || p->comm)) {
+  if (!fn && streaming && p->entry != wide_entry(p->dtype) && (nv >= 3 || p->comm)) {
     if (iters == 0) return FOS_OK;
     return run_multi_mfma(fs, nv, iters);          // 5..16 weights, n up to 16384, fp32 and bf16
   }

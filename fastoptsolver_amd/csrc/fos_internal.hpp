@@ -215,7 +215,7 @@ struct fos_fista {
 namespace fosapi {
 
 // ---- fos_plan.hip ---------------------------------------------------------------------------------------------------
-const MenuEntry* wide_entry();                    // the y-in-LDS pass for 16385..32768 fp32 columns (gemv_wide.hpp)
+const MenuEntry* wide_entry(int dtype);           // the y-in-LDS pass (gemv_wide.hpp): 16385..32768 fp32, 24577..32768 bf16 columns
 const MenuEntry* find_entry(int dtype, int threads, int k, int r);
 const MenuEntry* default_entry(int dtype, int64_t n);
 int epc_of(int dtype);

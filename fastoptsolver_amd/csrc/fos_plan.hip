@@ -106,14 +106,31 @@ const DdEntry kDdMenu[] = {
 // The 64-thread entries give narrow rows (65..512 columns) one WAVE per row instead of a 256-thread workgroup whose
 // lanes would mostly idle (200000 x 256 ran at 18 % of the roofline on the 256-thread geometry); they are launched
 // with proportionally more workgroups (plan_fused).
+// Three-chunk geometries (round 3): a chunk beyond n is not idle - it re-reads the thread's chunk 0 to keep the loads
+// branch-free - so a width of 3 * 2^k columns on the next power-of-two geometry paid for a quarter more load instructions
+// (fp32 12288 columns 75 %, 10240 70 % of 8 TB/s against 84 % at 16384: tools/bench_widths.py).  Capacities are now
+// 1, 2, 3, 4, 5, 6, 8, 10, 12, 14, 16 x 1024 columns (fp32), so from 2048 columns on at least 4/5 of the issued loads are
+// live at any width (n = 5000 and 10000 land on the five-chunk geometries at 98 %).
+// bf16 rows of 16385 ... 24576 columns get 512 threads x 6 chunks (1024 threads at 128 VGPRs spill; 8 chunks - y and the
+// gradient slice 64 VGPRs each - spill at 256), 24577 ... 32768 the y-in-LDS kernel (gemv_wide.hpp), instead of two passes in
+// column blocks (36 % of the roofline -> a single read).
+#define ENTRY_IL_ND(DT, T, TH, K, R, W) \
+  { DT, TH, K, R, PAIR(T, TH, K, R, W, 2, false, false, false), nullptr, nullptr, \
+    PAIR(T, TH, K, R, W, 2, false, true, false), PAIR(T, TH, K, R, W, 2, false, false, true), nullptr }
 const MenuEntry kMenu[] = {
     ENTRY_D(FOS_F32, float, 64, 1, 4, 2), ENTRY_D(FOS_F32, float, 64, 2, 4, 2),
-    ENTRY_D(FOS_F32, float, 256, 1, 4, 2), ENTRY_D(FOS_F32, float, 256, 2, 4, 2), ENTRY_D(FOS_F32, float, 256, 4, 2, 2),
-    ENTRY_NB_IL(FOS_F32, float, 512, 4, 1, 2, 3),   ENTRY_DRAIN(FOS_F32, float, 1024, 4, 1, 4, 512, 8, 2),
+    ENTRY_D(FOS_F32, float, 256, 1, 4, 2), ENTRY_D(FOS_F32, float, 256, 2, 4, 2), ENTRY_D(FOS_F32, float, 256, 3, 2, 2),
+    ENTRY_D(FOS_F32, float, 256, 4, 2, 2), ENTRY_D(FOS_F32, float, 256, 5, 2, 2),
+    ENTRY_NB_IL(FOS_F32, float, 512, 3, 1, 2, 3),   ENTRY_NB_IL(FOS_F32, float, 512, 4, 1, 2, 3),
+    ENTRY_NB_IL(FOS_F32, float, 512, 5, 1, 2, 3),   ENTRY_DRAIN(FOS_F32, float, 1024, 3, 1, 4, 512, 6, 2),
+    ENTRY_NB_IL(FOS_F32, float, 512, 7, 1, 2, 2),   ENTRY_DRAIN(FOS_F32, float, 1024, 4, 1, 4, 512, 8, 2),
     ENTRY_D(FOS_F32, float, 512, 8, 1, 2),  ENTRY(FOS_F32, float, 1024, 2, 2, 4),
     ENTRY(FOS_BF16, fos::bf16_t, 64, 1, 4, 2),                      // one wave per row: up to 512 bf16 columns
     ENTRY(FOS_BF16, fos::bf16_t, 256, 1, 4, 2), ENTRY(FOS_BF16, fos::bf16_t, 256, 2, 2, 2),
-    ENTRY_NB_IL(FOS_BF16, fos::bf16_t, 256, 4, 1, 2, 3), ENTRY_NB_IL(FOS_BF16, fos::bf16_t, 512, 4, 1, 2, 3),
+    ENTRY_NB_IL(FOS_BF16, fos::bf16_t, 256, 3, 1, 2, 3), ENTRY_NB_IL(FOS_BF16, fos::bf16_t, 256, 4, 1, 2, 3),
+    ENTRY_IL_ND(FOS_BF16, fos::bf16_t, 256, 5, 1, 2),
+    ENTRY_NB_IL(FOS_BF16, fos::bf16_t, 512, 3, 1, 2, 3), ENTRY_NB_IL(FOS_BF16, fos::bf16_t, 512, 4, 1, 2, 3),
+    ENTRY_IL_ND(FOS_BF16, fos::bf16_t, 512, 5, 1, 2), ENTRY_IL_ND(FOS_BF16, fos::bf16_t, 512, 6, 1, 2),
 };
 
 const MenuEntry* find_entry(int dtype, int threads, int k, int r) {
@@ -128,17 +145,20 @@ const MenuEntry* default_entry(int dtype, int64_t n) {
   return nullptr;
 }
 
-// ---- wide rows (gemv_wide.hpp): 16384 < n <= 32768 fp32, y in LDS (dynamic shared memory above the 64 KiB default) ---
-template <bool WITH_G>
+// ---- wide rows (gemv_wide.hpp): y in LDS (dynamic shared memory above the 64 KiB default): 16384 < n <= 32768 fp32,
+// 24576 < n <= 32768 bf16 ---
+template <bool WITH_G, typename T>
 void wide_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, float* slabs,
                  double* rr_part, double* /*rr2_part*/, int nwg, hipStream_t st) {
   static std::atomic<uint64_t> done{0};
-  (void)raise_dynamic_lds(&fos::gemv_wide_kernel<WITH_G>, fos::WD_MAX_N * sizeof(float), done);   // failure: see LAUNCH_CHECK
-  hipLaunchKernelGGL((fos::gemv_wide_kernel<WITH_G>), dim3(nwg), dim3(fos::WD_THREADS), (size_t)n * sizeof(float), st,
-                     reinterpret_cast<const float*>(A), lda, b, m, n, ys, rpw, slabs, rr_part);
+  (void)raise_dynamic_lds(&fos::gemv_wide_kernel<WITH_G, T>, fos::WD_MAX_N * sizeof(float), done);   // failure: see LAUNCH_CHECK
+  hipLaunchKernelGGL((fos::gemv_wide_kernel<WITH_G, T>), dim3(nwg), dim3(fos::WD_THREADS), (size_t)n * sizeof(float), st,
+                     reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part);
 }
-const MenuEntry kWideF32 = {FOS_F32, fos::WD_THREADS, fos::WD_K, 1, wide_launch<true>, wide_launch<false>, nullptr};
-const MenuEntry* wide_entry() { return &kWideF32; }
+const MenuEntry kWideF32 = {FOS_F32, fos::WD_THREADS, fos::WD_K, 1, wide_launch<true, float>, wide_launch<false, float>, nullptr};
+const MenuEntry kWideBf16 = {FOS_BF16, fos::WD_THREADS, fos::WD_K / 2, 1, wide_launch<true, fos::bf16_t>,
+                             wide_launch<false, fos::bf16_t>, nullptr};
+const MenuEntry* wide_entry(int dtype) { return dtype == FOS_F32 ? &kWideF32 : &kWideBf16; }
 
 // ---- tall-skinny entries (gemv_tall.hpp): n <= 64, any m / lda; one entry per column capacity and load form --------
 template <typename T, int NC, int LOAD, bool WITH_G, bool DUAL>
@@ -689,7 +709,7 @@ void apply_plan(fos_problem* p, unsigned flags) {
   if (n <= fos::TL_MAX_N && !(flags & FOS_PLAN_NO_TALL))
     plan_tall(p, tall_entry(p->dtype, n, p->lda, p->A));
   else if (e) plan_fused(p, e, 0);
-  else if (vec_ok && p->dtype == FOS_F32 && n <= fos::WD_MAX_N && !(flags & FOS_PLAN_NO_WIDE)) plan_fused(p, &kWideF32, 0);
+  else if (vec_ok && n <= fos::WD_MAX_N && !(flags & FOS_PLAN_NO_WIDE)) plan_fused(p, wide_entry(p->dtype), 0);
   else if (vec_ok && !(flags & FOS_PLAN_NO_COLBLOCK)) {
     // column blocks of equal width (a multiple of 64 columns, at most the widest streaming geometry)
     const int64_t cap = 16384;

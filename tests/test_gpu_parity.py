@@ -733,11 +733,11 @@ def test_wide_rows(fos, m, n, kind):
 
 
 def test_wide_rows_bf16_and_sharded_column_blocks(fos):
-    """bf16 rows beyond 16384 columns take the column-blocked passes too; with a communicator attached the blocks' slabs
+    """bf16 rows beyond 32768 columns take the column-blocked passes too; with a communicator attached the blocks' slabs
     go through the same slab reduction + all-reduce as any other plan."""
     from fastoptsolver_amd import distributed as fd
     rng = np.random.default_rng(9)
-    m, n = 150, 20000
+    m, n = 150, 40000
     A16 = torch.as_tensor(rng.standard_normal((m, n)).astype(np.float32)).to(torch.bfloat16).cuda()
     A64 = A16.to(torch.float64).cpu().numpy()
     b = rng.standard_normal(m).astype(np.float32)
@@ -754,6 +754,43 @@ def test_wide_rows_bf16_and_sharded_column_blocks(fos):
     x_c = fos.fista(A16, b, "elasticnet", 3.0, 0.5, max_iter=15, L=L, comm=comm, backtracking=True, t_init_factor=2.0)
     x_bt = orc.fista(A64, b.astype(np.float64), "elasticnet", 3.0, 0.5, max_iter=15, L=L, backtracking=True, t_init_factor=2.0)
     assert _data.rel(_np(x_c), x_bt) < TOL
+
+
+@pytest.mark.parametrize("kind,m,n,geo", [
+    ("f32", 300, 2560, (256, 3)), ("f32", 257, 3072, (256, 3)), ("f32", 515, 5000, (256, 5)), ("f32", 260, 6144, (512, 3)),
+    ("f32", 300, 10000, (512, 5)), ("f32", 259, 12288, (1024, 3)), ("f32", 131, 12292, (512, 7)), ("f32", 140, 14336, (512, 7)),
+    ("bf16", 300, 5120, (256, 3)), ("bf16", 257, 6144, (256, 3)), ("bf16", 300, 12288, (512, 3)), ("bf16", 260, 10000, (256, 5)),
+    ("bf16", 150, 20000, (512, 5)), ("bf16", 130, 24576, (512, 6)), ("bf16", 131, 24584, (512, 8)), ("bf16", 200, 32768, (512, 8))])
+def test_three_chunk_geometries_and_bf16_wide_rows(fos, kind, m, n, geo):
+    """Round 3: widths between the powers of two get geometries of three, five or seven chunks per thread (a chunk beyond n is
+    a re-read, not an idle lane) and bf16 rows of 16385 ... 32768 columns a single read - 512 x 6 chunks up to 24576, the y-in-LDS kernel
+    (reported as 512 x 8) above - instead of column blocks.  Gradient, residual, FISTA with every flag and the history
+    objective against the oracle; the planner lands on the expected geometry."""
+    rng = np.random.default_rng(m + n)
+    At = torch.as_tensor(rng.standard_normal((m, n)).astype(np.float32)).to(torch.bfloat16 if kind == "bf16" else torch.float32).cuda()
+    A64 = At.to(torch.float64).cpu().numpy()
+    b = rng.standard_normal(m).astype(np.float32)
+    y = rng.standard_normal(n).astype(np.float32)
+    prob = fos.prepare(At, b, pad=False)
+    plan = prob.plan()
+    assert plan["path"] == 0 and plan["colblock"] == 0 and (plan["threads"], plan["chunks"]) == geo, plan
+    b64 = b.astype(np.float64)
+    g_ref, rr_ref = orc.gram_gradient(A64, y.astype(np.float64), b64, 0.3)
+    assert _data.rel(prob.gemv_pair(_dev(y), alpha2=0.3).cpu().numpy(), g_ref) < TOL
+    assert prob.residual_objective(_dev(y))[0] == pytest.approx(rr_ref, rel=TOL)
+    L = float(np.linalg.norm(A64, 2) ** 2)
+    lam = float(np.max(np.abs(A64.T @ b64)))
+    for kw in (dict(), dict(adaptive_restart=True, tol_ratio=0.5), dict(backtracking=True, t_init_factor=2.0),
+               dict(return_history=True)):
+        out = fos.fista(prob, None, "elasticnet", 0.1 * lam, 0.4, max_iter=15, L=L, **kw)
+        ref = orc.fista(A64, b64, "elasticnet", 0.1 * lam, 0.4, max_iter=15, L=L, **kw)
+        x, x_ref = (out[0], ref[0]) if kw.get("return_history") else (out, ref)
+        assert _data.rel(_np(x), x_ref) < TOL, kw
+        if kw.get("return_history"):
+            assert np.allclose(out[1]["obj"], ref[1]["obj"], rtol=TOL)
+    s = fos.LBFGSSolver("ridge", 0.0, 1.0, max_iter=6).fit(prob, None)
+    r = orc.LBFGSSolver("ridge", 0.0, 1.0, max_iter=6).fit(A64, b64)
+    assert _data.rel(_np(s.x_), r.x_) < TOL
 
 
 def test_armijo_constant_is_read_at_call_time(fos, monkeypatch):
