@@ -60,10 +60,12 @@ void fused_launch_dd(const void* A, int64_t lda, const float* b, int64_t m, int 
 const DdEntry kDdMenu[] = {
     DD_ENTRY(FOS_F32, float, 64, 1, 4, false), DD_ENTRY(FOS_F32, float, 64, 2, 2, false),
     DD_ENTRY(FOS_F32, float, 256, 1, 2, false), DD_ENTRY(FOS_F32, float, 256, 2, 2, false),
-    DD_ENTRY_IL(FOS_F32, float, 256, 4, 1, false), DD_ENTRY3_IL(FOS_F32, float, 512, 4, 1, false),
-    DD_ENTRY_IL(FOS_F32, float, 512, 8, 1, true),
+    DD_ENTRY(FOS_F32, float, 256, 3, 1, false),            // (3, 5 chunks: widths between the powers of two, as in kMenu: +3-5 %)
+    DD_ENTRY_IL(FOS_F32, float, 256, 4, 1, false), DD_ENTRY_IL(FOS_F32, float, 512, 3, 1, false),
+    DD_ENTRY3_IL(FOS_F32, float, 512, 4, 1, false), DD_ENTRY_IL(FOS_F32, float, 512, 5, 1, false),
+    DD_ENTRY_IL(FOS_F32, float, 512, 8, 1, true),          // (512 x 6 with y in LDS measured 3 % behind this one at 12288 columns)
     DD_ENTRY(FOS_BF16, fos::bf16_t, 64, 1, 2, false), DD_ENTRY(FOS_BF16, fos::bf16_t, 256, 1, 2, false),
-    DD_ENTRY(FOS_BF16, fos::bf16_t, 256, 2, 1, false),
+    DD_ENTRY(FOS_BF16, fos::bf16_t, 256, 2, 1, false), DD_ENTRY_IL(FOS_BF16, fos::bf16_t, 256, 3, 1, false),
     // bf16 rows of 4 chunks per thread: the pass is VALU-bound (56 VALU instructions per 16-byte chunk: unpack + convert
     // for the dot, AGAIN for the gradient update, 16 v_fma_f64), so these keep the converted tile across the barrier
     // (KEEPCVT: 40 instructions) and pay with registers - two tiles in flight instead of three, per-chunk scheduling
@@ -71,6 +73,7 @@ const DdEntry kDdMenu[] = {
     // 131072 x 16384 66.6 -> 74.5 %.
     { FOS_BF16, 256, 4, 1, fused_launch_dd<fos::bf16_t, 256, 4, 1, 2, true, 2, false, true>,
       fused_launch_dd<fos::bf16_t, 256, 4, 1, 2, true, 2, true, true> },
+    DD_ENTRY_IL(FOS_BF16, fos::bf16_t, 512, 3, 1, false),
     { FOS_BF16, 512, 4, 1, fused_launch_dd<fos::bf16_t, 512, 4, 1, 2, true, 2, false, true>,
       fused_launch_dd<fos::bf16_t, 512, 4, 1, 2, true, 2, true, true> },
 };

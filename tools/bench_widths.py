@@ -8,6 +8,7 @@ import fastoptsolver_amd as fos
 from fastoptsolver_amd import _core
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "f32"
+dd = len(sys.argv) > 2 and sys.argv[2] == "dd"          # the fp64-accumulating pass (L-BFGS fg) instead of the FISTA step
 esz = 4 if kind == "f32" else 2
 torch.cuda.set_device(0)
 widths = [2048, 2560, 3072, 3584, 4096, 5120, 6144, 7168, 8192, 10240, 12288, 14336, 16384]
@@ -21,17 +22,25 @@ for n in widths:
         A = A.to(torch.bfloat16)
     b = torch.randn(m, device="cuda", generator=g)
     prob = fos.prepare(A, b)
-    st = _core.Fista(prob); st.reset(1e-9, 1.0, 0.0)
-    st.run(10); torch.cuda.synchronize()
+    if dd:
+        from fastoptsolver_amd import _lib
+        x64 = torch.randn(n, dtype=torch.float64, device="cuda")
+        out64 = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
+        run = lambda k: [_lib.check(prob.lib.fos_gemv_pair_dd(prob.h, _core.ptr(x64), 0.5, _core.ptr(out64))) for _ in range(k)]
+        st = None
+    else:
+        st = _core.Fista(prob); st.reset(1e-9, 1.0, 0.0)
+        run = st.run
+    run(10); torch.cuda.synchronize()
     best = 1e30
     for _ in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); st.run(100); e1.record(); e1.synchronize()
-        best = min(best, e0.elapsed_time(e1) * 10.0)
-    byt = m * n * esz + 4 * m + 16 * n
+        e0.record(); run(50); e1.record(); e1.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 20.0)
+    byt = m * n * esz + 4 * m + (8 if dd else 16) * n
     pl = prob.plan()
     cap = pl["threads"] * pl["chunks"] * (16 // esz)
-    print(f"{kind} {m}x{n}: {best:7.1f} us = {byt / best / 8e4:5.1f} % of 8 TB/s   plan {pl['threads']}x{pl['chunks']} rows {pl['rows']} "
+    print(f"{kind}{' fg(fp64)' if dd else ''} {m}x{n}: {best:7.1f} us = {byt / best / 8e4:5.1f} % of 8 TB/s   plan {pl['threads']}x{pl['chunks']} rows {pl['rows']} "
           f"(capacity {cap}, {100.0 * n / cap:.0f} % of the lanes busy), {pl['workgroups']} wg", flush=True)
     del st, prob, A, b
     torch.cuda.empty_cache()
