@@ -783,7 +783,7 @@ int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters) {
     const fos::FistaParams &a = fs[0]->prm, &c = fs[v]->prm;
     same_family = same_family && a.mode == c.mode && a.prox_kind == c.prox_kind && a.delta == c.delta;
   }
-  const bool shape_ok = p->path == 0 && !p->tall && !p->colblock && !p->resident && !p->col_sharded;
+  const bool shape_ok = batch_supported(p) && !p->colblock && !p->resident && !p->col_sharded;
   // Column-sharded (very wide A): the two products per panel with ONE exchange of the panel's 16 residual columns between
   // them; always device-controlled (step norms are sums over the ranks).  The matrix-core kernels tile any width.
   if (p->col_sharded) {
@@ -799,7 +799,7 @@ int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters) {
   }
   const bool streaming = shape_ok && all_plain;
   // (a sharded problem takes the matrix-core pass for any number of weights: its 16 gradients are one 16 x n all-reduce)
-  MultiLaunch fn = (streaming && !p->comm && p->dtype == FOS_F32 && p->entry != wide_entry(p->dtype)) ? find_multi(p->n, nv) : nullptr;
+  MultiLaunch fn = (streaming && !p->tall && !p->comm && p->dtype == FOS_F32 && p->entry != wide_entry(p->dtype)) ? find_multi(p->n, nv) : nullptr;
   // the two-product pass costs about two single-vector passes per iteration whatever the number of weights: it pays
   // from three weights on (profiles/r02_multilambda.md); two weights without a VALU multi-vector kernel run one by one
   if (!fn && streaming && p->entry != wide_entry(p->dtype) && (nv >= 3 || p->comm)) {

@@ -216,8 +216,8 @@ void tallr_launch_dd(const void* A, int64_t lda, const float* b, int64_t m, int 
   { DT, fos::TL_THREADS, LPR, 0, tallr_launch<T, LPR, true, false>, tallr_launch<T, LPR, false, false>, \
     tallr_launch<T, LPR, true, true>, tallr_launch_dd<T, LPR> }
 // (a row per 4 lanes - up to 4 chunks - measured slower than the row-per-thread form and is not instantiated)
-const MenuEntry kTallRowsF32[2] = {TALLR(FOS_F32, float, 8), TALLR(FOS_F32, float, 16)};
-const MenuEntry kTallRowsBf16[1] = {TALLR(FOS_BF16, fos::bf16_t, 8)};
+const MenuEntry kTallRowsF32[3] = {TALLR(FOS_F32, float, 8), TALLR(FOS_F32, float, 16), TALLR(FOS_F32, float, 32)};
+const MenuEntry kTallRowsBf16[2] = {TALLR(FOS_BF16, fos::bf16_t, 8), TALLR(FOS_BF16, fos::bf16_t, 16)};
 #undef TALLR
 // 33..64 columns: a row per quad of lanes (gemv_tall_quad_kernel)
 #define TALLQ(DT, T, VEC) \
@@ -246,9 +246,11 @@ const MenuEntry* tall_entry(int dtype, int64_t n, int64_t lda, const void* A) {
   // (4000000 x 32: 52 % -> 74 % of the roofline, 2000000 x 64: 53 % -> 73 %).  Up to 4 chunks the row-per-thread form
   // with 16-byte loads is the faster one (4000000 x 16: 72-76 % against 67-69 %, profiles/r02_sweep_wgs.log).
   if (n % epc == 0 && lda % epc == 0 && (reinterpret_cast<uintptr_t>(A) & 15u) == 0 && n / epc > 4) {
+    // (round 3) 65..128 columns: a row per 32 lanes (fp32) / 16 lanes (bf16) - on the one-wave-per-row streaming geometry
+    // a 72-column row left 46 of 64 lanes re-reading chunk 0 (53 % of 8 TB/s at 7456512 x 72; tools/bench_widths.py narrow)
     const int chunks = (int)(n / epc);
-    if (dtype == FOS_F32) return &kTallRowsF32[chunks <= 8 ? 0 : 1];
-    return &kTallRowsBf16[0];
+    if (dtype == FOS_F32) return &kTallRowsF32[chunks <= 8 ? 0 : chunks <= 16 ? 1 : 2];
+    return &kTallRowsBf16[chunks <= 8 ? 0 : 1];
   }
   const int idx = n <= 8 ? 0 : n <= 16 ? 1 : n <= 32 ? 2 : 3;
   const bool contiguous = (lda == n);
@@ -669,7 +671,9 @@ MultiLaunch find_multi(int64_t n, int nv) {
   return nullptr;
 }
 
-bool batch_supported(const fos_problem* p) { return p->path == 0 && !p->tall; }   // fp32: f32 MFMA; bf16: 3-term bf16 MFMA
+// The matrix-core passes (16 candidates / 16 weights) need the aligned layout only - not a streaming plan: rows of 65..128
+// columns run the chunk-per-lane pass (p->tall) and keep them; n <= 64 may be ragged / misaligned and does not.
+bool batch_supported(const fos_problem* p) { return p->path == 0 && (!p->tall || p->n > fos::TL_MAX_N); }   // fp32: f32 MFMA; bf16: 3-term bf16 MFMA
 
 // A caller vector the fused prologue can read with 16-byte loads.
 int aligned_vec(fos_problem* p, const float* v, const float** out) {
@@ -709,7 +713,7 @@ void apply_plan(fos_problem* p, unsigned flags) {
   const int epc = epc_of(p->dtype);
   const bool vec_ok = (n % epc == 0) && (p->lda % epc == 0) && ((reinterpret_cast<uintptr_t>(p->A) & 15u) == 0);
   const MenuEntry* e = vec_ok ? default_entry(p->dtype, n) : nullptr;
-  if (n <= fos::TL_MAX_N && !(flags & FOS_PLAN_NO_TALL))
+  if ((n <= fos::TL_MAX_N || (n <= fos::TLR_MAX_N && vec_ok)) && !(flags & FOS_PLAN_NO_TALL))
     plan_tall(p, tall_entry(p->dtype, n, p->lda, p->A));
   else if (e) plan_fused(p, e, 0);
   else if (vec_ok && n <= fos::WD_MAX_N && !(flags & FOS_PLAN_NO_WIDE)) plan_fused(p, wide_entry(p->dtype), 0);
@@ -855,8 +859,8 @@ int fos_problem_set_comm_cols(fos_problem* p, fos_comm* c) {
   if (!p || !c) return fail(FOS_ERR_ARG, "fos_problem_set_comm_cols: null");
   const int epc = epc_of(p->dtype);
   const bool vec_ok = (p->n % epc == 0) && (p->lda % epc == 0) && ((reinterpret_cast<uintptr_t>(p->A) & 15u) == 0);
-  if (!vec_ok || p->n <= fos::TL_MAX_N)
-    return fail(FOS_ERR_UNSUPPORTED, "fos_problem_set_comm_cols: needs the streaming layout (aligned, n > 64 per rank)");
+  if (!vec_ok || p->n <= fos::TLR_MAX_N)
+    return fail(FOS_ERR_UNSUPPORTED, "fos_problem_set_comm_cols: needs the streaming layout (aligned, n > 128 per rank)");
   // the two-phase column-block plan, whatever the width: r = sum_p A_p y_p - b is exchanged between the phases
   void* drop[] = {p->slabs, p->rr_part, p->rr2_part};
   for (void* q : drop)

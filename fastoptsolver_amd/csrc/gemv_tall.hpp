@@ -20,6 +20,7 @@ namespace fos {
 
 constexpr int TL_THREADS = 256;
 constexpr int TL_MAX_N = 64;
+constexpr int TLR_MAX_N = 128;          // aligned rows, chunk per lane: up to 32 lanes per row (gemv_tall_rows_kernel)
 __host__ __device__ inline int tall_slab_stride(int n) { return (n + 3) & ~3; }
 
 // NC: compile-time column capacity (8/16/32/64; columns beyond n are zero).  LOAD: how a thread gets its row -
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(TL_THREADS) void gemv_tall_quad_kernel(const T* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Aligned tall-skinny rows (n <= 64, n and lda multiples of 16 bytes, A 16-byte aligned): a row per LPR lanes, every
+// Aligned tall-skinny rows (n <= 128, n and lda multiples of 16 bytes, A 16-byte aligned): a row per LPR lanes, every
 // lane owns ONE 16-byte chunk of the row (4 fp32 / 8 bf16 columns).  A wave's load instruction then reads 64 consecutive
 // chunks = 1 KiB of contiguous memory when lda == n (the row-per-thread and row-per-quad forms above touch 16 bytes of 64
 // different rows / a quarter of every line per instruction and reach 52 % / 53 % of the roofline at n = 32 / 64), the
@@ -320,12 +321,13 @@ __global__ __launch_bounds__(TL_THREADS) void gemv_tall_quad_kernel(const T* __r
 // ---------------------------------------------------------------------------------------------------------
 template <int LPR>
 __device__ inline double lanes_sum(double v) {
-  static_assert(LPR == 4 || LPR == 8 || LPR == 16, "LPR");
+  static_assert(LPR == 4 || LPR == 8 || LPR == 16 || LPR == 32, "LPR");
   v += dpp_fetch<0xB1, 0xF>(v);                         // quad_perm [1,0,3,2]
   v += dpp_fetch<0x4E, 0xF>(v);                         // quad_perm [2,3,0,1]
   if constexpr (LPR >= 8) v += dpp_fetch<0x141, 0xF>(v);   // row_half_mirror
   if constexpr (LPR >= 16) v += dpp_fetch<0x140, 0xF>(v);  // row_mirror
-  return v;
+  if constexpr (LPR >= 32) v += __shfl_xor(v, 16);         // the other 16-lane row of the pair (no DPP pattern crosses rows
+  return v;                                                //  both ways on this ISA: one ds_bpermute pair per row step)
 }
 
 template <typename T, int LPR, bool WITH_G, bool DUAL, typename ST = float>

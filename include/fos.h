@@ -94,7 +94,7 @@ int fos_problem_destroy(fos_problem* p);
 int fos_problem_set_stream(fos_problem* p, void* stream);
 /* plan[0..7] = {path (0 fused single pass, 1 two-pass fallback), threads, chunks/thread, rows/step,
  *               workgroups, slabs, flags (bit 0: non-temporal loads; bit 1: small enough for the single-launch
- *               LDS-resident loop that fos_fista_run / _run_history / fos_power_iter then use; bit 2: n <= 64, the
+ *               LDS-resident loop that fos_fista_run / _run_history / fos_power_iter then use; bit 2: n <= 64 (or aligned rows of up to 128 columns), the
  *               single pass is the row-per-thread kernel, which has no alignment requirements; bit 3: rows wider than
  *               any single-pass kernel - column blocks through the streaming kernel in two phases, A read twice;
  *               bit 4: set once fos_fista_run_multi has planned the one-read cluster form of the matrix-core pass;

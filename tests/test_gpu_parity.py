@@ -1297,14 +1297,17 @@ def test_resident_loop_with_bf16_storage(fos):
 
 
 # --------------------------------------------------------------------------------------------------
-# tall-skinny single pass (n <= 64, row per thread): regression shapes with many samples and few features
+# tall-skinny single pass (n <= 64 row per thread; aligned rows up to 128 columns chunk per lane): many samples, few features
 # --------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m,n,kind", [(20000, 5, "f32"), (20001, 7, "f32"), (70000, 8, "f32"), (33333, 16, "f32"),
                                       (9000, 33, "f32"), (12345, 64, "f32"), (5000, 32, "strided"), (6000, 12, "bf16"),
                                       (200, 64, "f32"), (1, 40, "f32"),
                                       # aligned rows: a row per 4 / 8 / 16 lanes, one 16-byte chunk per lane
                                       (40001, 12, "f32"), (30000, 24, "f32"), (25000, 40, "f32"), (1027, 60, "f32"),
-                                      (7000, 48, "strided"), (9000, 16, "bf16"), (8000, 40, "bf16"), (5003, 64, "bf16")])
+                                      (7000, 48, "strided"), (9000, 16, "bf16"), (8000, 40, "bf16"), (5003, 64, "bf16"),
+                                      # round 3: 65..128 columns, a row per 32 lanes (fp32) / 16 lanes (bf16)
+                                      (30001, 68, "f32"), (20000, 100, "f32"), (9000, 128, "f32"), (3, 72, "f32"),
+                                      (7001, 120, "strided"), (8000, 72, "bf16"), (5003, 128, "bf16")])
 def test_tall_skinny_gemv_pair(fos, m, n, kind):
     rng = np.random.default_rng(m + n)
     A = rng.standard_normal((m, n)).astype(np.float32)
@@ -1341,6 +1344,20 @@ def test_tall_skinny_gemv_pair(fos, m, n, kind):
         x_ref, h_ref = orc.fista(A.astype(np.float64), b.astype(np.float64), "lasso", 0.05 * lam, 0.0, max_iter=12, L=L,
                                  return_history=True, adaptive_restart=True)
         assert _data.rel(_np(x), x_ref) < TOL and np.allclose(h["obj"], h_ref["obj"], rtol=TOL)
+        if n > 64:           # aligned rows of 65..128 columns keep the matrix-core passes: 16 candidates, 16 weights
+            A64, b64 = A.astype(np.float64), b.astype(np.float64)
+            xb = fos.fista(prob, None, "elasticnet", 0.05 * lam, 0.3, max_iter=12, L=L, backtracking=True, t_init_factor=2.0)
+            xb_ref, met = orc.fista(A64, b64, "elasticnet", 0.05 * lam, 0.3, max_iter=12, L=L, backtracking=True,
+                                    t_init_factor=2.0, return_metrics=True)
+            # (shrink counts: equal except for the length of the reference's ~50-halving step-underflow event, which is
+            #  decided by fp64 rounding noise - see _check_linesearch_counts; the streaming plan gives the same count)
+            from fastoptsolver_amd import iterative_solvers as its
+            per_search = list(its.ls_call_iters)
+            slack = 25 if max(per_search) >= 25 else 0
+            assert _data.rel(_np(xb), xb_ref) < TOL and abs(sum(per_search) - met["ls_iters_total"]) <= slack, per_search
+            alphas = [(lam * 0.3 * 0.7 ** i, 0.2 if i % 2 else 0.0) for i in range(6)]
+            for x_j, (p1, p2) in zip(fos.fista_path(prob, None, alphas, max_iter=15, L=L), alphas):
+                assert _data.rel(_np(x_j), orc.fista(A64, b64, "elasticnet", p1, p2, max_iter=15, L=L)) < TOL
 
 
 def test_tall_skinny_solvers_on_unstandardised_features(fos):

@@ -14,6 +14,8 @@ torch.cuda.set_device(0)
 widths = [2048, 2560, 3072, 3584, 4096, 5120, 6144, 7168, 8192, 10240, 12288, 14336, 16384]
 if kind == "bf16":
     widths += [20480, 24576, 28672, 32768]
+if "narrow" in sys.argv:
+    widths = [72, 96, 128, 192, 256, 320, 384, 512, 640, 768, 1024, 1280, 1536, 1792, 2048]
 for n in widths:
     m = (1 << 31) // (n * 4) // 256 * 256              # ~2 GiB of fp32 (1 GiB of bf16)
     g = torch.Generator(device="cuda").manual_seed(n)
