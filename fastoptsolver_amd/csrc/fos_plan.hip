@@ -123,7 +123,7 @@ const DdEntry kDdMenu[] = {
 const MenuEntry kMenu[] = {
     ENTRY_D(FOS_F32, float, 64, 1, 4, 2), ENTRY_D(FOS_F32, float, 64, 2, 4, 2),
     ENTRY_D(FOS_F32, float, 256, 1, 4, 2), ENTRY_D(FOS_F32, float, 256, 2, 4, 2), ENTRY_D(FOS_F32, float, 256, 3, 2, 2),
-    ENTRY_D(FOS_F32, float, 256, 4, 2, 2), ENTRY_D(FOS_F32, float, 256, 5, 2, 2),
+    ENTRY_D(FOS_F32, float, 256, 4, 2, 2), ENTRY_NB_IL(FOS_F32, float, 256, 5, 2, 2, 2),
     ENTRY_NB_IL(FOS_F32, float, 512, 3, 1, 2, 3),   ENTRY_NB_IL(FOS_F32, float, 512, 4, 1, 2, 3),
     ENTRY_NB_IL(FOS_F32, float, 512, 5, 1, 2, 3),   ENTRY_DRAIN(FOS_F32, float, 1024, 3, 1, 4, 512, 6, 2),
     ENTRY_NB_IL(FOS_F32, float, 512, 7, 1, 2, 2),   ENTRY_DRAIN(FOS_F32, float, 1024, 4, 1, 4, 512, 8, 2),
