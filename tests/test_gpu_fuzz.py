@@ -234,9 +234,11 @@ def test_backtracking_sweep_coverage_report():
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FOS_FUZZ_SHAPE_SEEDS", "40"))))
 def test_random_shapes_and_layouts_gemv_pair(fos, seed):
     """The single pass over A through whatever kernel the planner picks - resident / row-per-thread (n <= 64),
-    one-wave-per-row (65..512), wide streaming geometries, two-pass - on random shapes, row strides and alignments."""
+    chunk-per-lane (aligned rows up to 128 columns), one-wave-per-row (..512), streaming geometries of 1..8 chunks per
+    thread, two-pass - on random shapes, row strides and alignments."""
     rng = np.random.default_rng(5000 + seed)
-    n = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 31, 32, 33, 63, 64, 65, 100, 128, 255, 256, 260, 511, 512, 516, 700, 1024, 1500]))
+    n = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 31, 32, 33, 63, 64, 65, 100, 128, 255, 256, 260, 511, 512, 516, 700, 1024, 1500,
+                        68, 96, 120, 2052, 2560, 3000, 5000, 6148, 10000, 12288, 14000]))    # round 3: 3/5/7-chunk geometries, 65..128
     m = int(rng.choice([1, 2, 7, 64, 255, 256, 257, 1000, 4096, 4097, 10000, 30001]))
     pad = int(rng.choice([0, 0, 1, 3, 4, 8]))                 # extra floats between rows (lda = n + pad)
     off = int(rng.choice([0, 0, 1, 4]))                       # start offset in floats (16-byte alignment or not)
