@@ -27,7 +27,13 @@ SHAPES = [
     ("shard 131072x16384 f32", 131072, 16384, "f32", ("f32", "dd")),
     ("shard 131072x16384 bf16", 131072, 16384, "bf16", ("f32", "dd")),
     ("wide 65536x32768 f32 (y in LDS)", 65536, 32768, "f32", ("f32",)),
-    ("narrow 1000000x128 f32 (one wave per row)", 1000000, 128, "f32", ("f32",)),
+    ("52224x10240 f32 (five chunks per thread)", 52224, 10240, "f32", ("f32", "dd")),
+    ("43520x12288 f32 (three chunks per thread, 1024 threads)", 43520, 12288, "f32", ("f32",)),
+    ("104704x5120 f32 (five chunks per thread)", 104704, 5120, "f32", ("f32",)),
+    ("43520x24576 bf16 (six chunks per thread)", 43520, 24576, "bf16", ("f32",)),
+    ("32768x32768 bf16 (y in LDS)", 32768, 32768, "bf16", ("f32",)),
+    ("narrow 1000000x128 f32 (chunk per lane, 32 lanes per row)", 1000000, 128, "f32", ("f32",)),
+    ("narrow 2000000x96 f32 (chunk per lane, 32 lanes per row)", 2000000, 96, "f32", ("f32",)),
     ("narrow 500000x512 f32 (one wave per row)", 500000, 512, "f32", ("f32",)),
     ("1048576x1024 f32", 1048576, 1024, "f32", ("f32", "dd")),
     ("tall 2000000x64 f32 (chunk per lane, 16 lanes per row)", 2000000, 64, "f32", ("f32",)),
