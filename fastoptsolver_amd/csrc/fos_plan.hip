@@ -804,6 +804,43 @@ int launch_cluster_pass(fos_problem* p) {
 }
 
 
+// Read-only streaming probe: what this box's HBM delivers to a kernel that does nothing but load (the context figure SURVEY.md
+// 8d asks for beside the nominal 8 TB/s).  The fastest of 18 x 4 loads-only variants (tools/read_probe_sweep.hip,
+// profiles/r03_read_probe_sweep.txt: 7.19 TB/s; grid-stride order 7.1, temporal loads 6.2, 4 workgroups per CU 6.1): one
+// 512-thread workgroup per CU streams its own contiguous range with 8 independent 16-byte non-temporal loads in flight per
+// thread - the access pattern of the single-pass kernel without its arithmetic.
+template <bool BLOCKS>
+__global__ __launch_bounds__(512) void stream_read_kernel(const fos::f32x4* __restrict__ src, size_t n16, float* __restrict__ sink) {
+  constexpr int UNR = 8, THREADS = 512;
+  fos::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (BLOCKS) {                               // every workgroup streams its own contiguous range
+    const size_t per = ((n16 + gridDim.x - 1) / gridDim.x + THREADS * UNR - 1) / (THREADS * UNR) * (THREADS * UNR);
+    const size_t lo = per * blockIdx.x, hi = lo + per < n16 ? lo + per : n16;
+    size_t i = lo + threadIdx.x;
+    for (; i + (size_t)(UNR - 1) * THREADS < hi; i += (size_t)UNR * THREADS) {
+      fos::f32x4 v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) v[u] = __builtin_nontemporal_load(src + i + (size_t)u * THREADS);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) acc += v[u];
+    }
+    for (; i < hi; i += THREADS) acc += __builtin_nontemporal_load(src + i);
+  } else {                                              // all workgroups sweep one window (the interleaved row order's pattern)
+    const size_t stride = (size_t)gridDim.x * THREADS;
+    size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    for (; i + (UNR - 1) * stride < n16; i += UNR * stride) {
+      fos::f32x4 v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) acc += v[u];
+    }
+    for (; i < n16; i += stride) acc += __builtin_nontemporal_load(src + i);
+  }
+  const float t = fos::wave_sum((acc.x + acc.y) + (acc.z + acc.w));
+  if ((threadIdx.x & 63) == 0) sink[blockIdx.x * 8 + (threadIdx.x >> 6)] = t;
+}
+
 }  // namespace fosapi
 
 using namespace fosapi;
@@ -923,29 +960,6 @@ int fos_problem_replan(fos_problem* p, unsigned flags) {
   return ensure_workspace(p);
 }
 
-// Read-only streaming probe: what this box's HBM delivers to a kernel that does nothing but load (the context figure SURVEY.md
-// 8d asks for beside the nominal 8 TB/s).  The fastest of 18 x 4 loads-only variants (tools/read_probe_sweep.hip,
-// profiles/r03_read_probe_sweep.txt: 7.19 TB/s; grid-stride order 7.1, temporal loads 6.2, 4 workgroups per CU 6.1): one
-// 512-thread workgroup per CU streams its own contiguous range with 8 independent 16-byte non-temporal loads in flight per
-// thread - the access pattern of the single-pass kernel without its arithmetic.
-__global__ __launch_bounds__(512) void stream_read_kernel(const fos::f32x4* __restrict__ src, size_t n16, float* __restrict__ sink) {
-  constexpr int UNR = 8, THREADS = 512;
-  const size_t per = ((n16 + gridDim.x - 1) / gridDim.x + THREADS * UNR - 1) / (THREADS * UNR) * (THREADS * UNR);
-  const size_t lo = per * blockIdx.x, hi = lo + per < n16 ? lo + per : n16;
-  size_t i = lo + threadIdx.x;
-  fos::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (; i + (size_t)(UNR - 1) * THREADS < hi; i += (size_t)UNR * THREADS) {
-    fos::f32x4 v[UNR];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) v[u] = __builtin_nontemporal_load(src + i + (size_t)u * THREADS);
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) acc += v[u];
-  }
-  for (; i < hi; i += THREADS) acc += __builtin_nontemporal_load(src + i);
-  const float t = fos::wave_sum((acc.x + acc.y) + (acc.z + acc.w));
-  if ((threadIdx.x & 63) == 0) sink[blockIdx.x * 8 + (threadIdx.x >> 6)] = t;
-}
-
 int fos_stream_read_probe(const void* buf, size_t bytes, int launches, void* stream, double* gbps_out, double* us_out) {
   if (!buf || bytes < 16 || (bytes & 15) || (reinterpret_cast<uintptr_t>(buf) & 15) || launches < 1 || !gbps_out)
     return fail(FOS_ERR_ARG, "fos_stream_read_probe: needs a 16-byte aligned buffer of a multiple of 16 bytes and launches >= 1");
@@ -960,18 +974,23 @@ int fos_stream_read_probe(const void* buf, size_t bytes, int launches, void* str
   hipEvent_t e0 = nullptr, e1 = nullptr;
   hipError_t e = hipEventCreate(&e0);
   if (e == hipSuccess) e = hipEventCreate(&e1);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(stream_read_kernel, dim3(grid), dim3(512), 0, st, (const fos::f32x4*)buf, n16, sink);      // warm-up
+  // both orders - contiguous ranges per workgroup, one window swept by all - and the faster one counts: which of the two
+  // leads depends on the size and on the state of the device (profiles/r03_row_order.md), as for the product kernel
+  float ms = 0.f;
+  for (int order = 0; order < 2 && e == hipSuccess; ++order) {
+    void (*kern)(const fos::f32x4*, size_t, float*) = order == 0 ? stream_read_kernel<true> : stream_read_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, st, (const fos::f32x4*)buf, n16, sink);      // warm-up
     e = hipEventRecord(e0, st);
     for (int i = 0; i < launches && e == hipSuccess; ++i) {
-      hipLaunchKernelGGL(stream_read_kernel, dim3(grid), dim3(512), 0, st, (const fos::f32x4*)buf, n16, sink);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, st, (const fos::f32x4*)buf, n16, sink);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipEventRecord(e1, st);
     if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float t = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+    if (e == hipSuccess && (order == 0 || t < ms)) ms = t;
   }
-  float ms = 0.f;
-  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
   (void)hipFree(sink);
