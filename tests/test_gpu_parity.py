@@ -1569,3 +1569,37 @@ def test_prepare_from_host_arrays(fos):
     x_nd = fos.fista(F, b, "lasso", 0.1 * lam, 0.0, max_iter=40, L=L)
     assert isinstance(x_nd, np.ndarray) and x_nd.dtype == np.float64
     assert _data.rel(x_nd, orc.fista(Ar, br, "lasso", 0.1 * lam, 0.0, max_iter=40, L=L)) < TOL
+
+
+def test_handles_release_their_device_memory(fos):
+    """Every workspace the library allocates under a problem / solver handle (slabs, fp64 slabs, candidate blocks, the
+    multi-lambda panels, L-BFGS workspace, persistent-step barriers) goes back with the handle: device memory in use after
+    40 rounds of create -> every solver family -> destroy equals the level after the first round."""
+    import gc
+    from fastoptsolver_amd import _core
+    A, b, _ = _data.synth(3000, 2048, 77)
+    At = torch.as_tensor(A.astype(np.float32)).cuda()
+    bt = b.astype(np.float32)
+    L = float(np.linalg.norm(A, 2) ** 2)
+    lam = float(np.max(np.abs(A.T @ b)))
+
+    def one_round():
+        prob = fos.prepare(At, bt)
+        fos.fista(prob, None, "lasso", 0.1 * lam, 0.0, max_iter=5, L=L)
+        fos.fista(prob, None, "elasticnet", 0.1 * lam, 0.5, max_iter=5, L=L, backtracking=True, return_history=True)
+        fos.fista_delta(prob, None, "lasso", 0.1 * lam, 0.0, 3.0, max_iter=5, L=L, tol_ratio=1e-9)
+        fos.fista_path(prob, None, [(0.1 * lam * 0.8 ** i, 0.0) for i in range(6)], max_iter=4, L=L)
+        fos.fista_path(prob, None, [(0.1 * lam * 0.8 ** i, 0.0) for i in range(3)], max_iter=4, L=L, adaptive_restart=True)
+        fos.LBFGSSolver("ridge", 0.0, 1.0, max_iter=3).fit(prob, None)
+        st = _core.Fista(prob); st.reset(1.0 / L, 0.1 * lam, 0.0)
+        assert st.run_fused(3)
+        del st, prob
+        gc.collect()
+        torch.cuda.synchronize()
+
+    one_round()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(40):
+        one_round()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), f"device memory in use grew by {(free0 - free1) / 2 ** 20:.1f} MiB over 40 rounds"
