@@ -1603,3 +1603,59 @@ def test_handles_release_their_device_memory(fos):
         one_round()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (8 << 20), f"device memory in use grew by {(free0 - free1) / 2 ** 20:.1f} MiB over 40 rounds"
+
+
+def test_distinct_handles_from_distinct_threads(fos):
+    """include/fos.h: "a handle is single-threaded; distinct handles may be used from distinct threads".  Four threads, each
+    with its own stream, problem (a different kernel family each: streaming fp32, bf16, chunk-per-lane, y-in-LDS) and solver
+    handle, run concurrently - plain and device-controlled loops and the fp64 pass; every result equals, bit for bit, what
+    the same calls give one after the other."""
+    import threading
+    from fastoptsolver_amd import _core, _lib
+    shapes = [(3000, 2048, torch.float32), (2500, 4096, torch.bfloat16), (40000, 100, torch.float32), (300, 20000, torch.float32)]
+    data = []
+    for i, (m, n, dt) in enumerate(shapes):
+        g = torch.Generator(device="cuda").manual_seed(100 + i)
+        A = torch.randn(m, n, device="cuda", generator=g).to(dt)
+        b = torch.randn(m, device="cuda", generator=g)
+        data.append((A, b, 1.0 / float((A.float() ** 2).sum())))
+
+    def work(i, out):
+        A, b, tau = data[i]
+        with torch.cuda.stream(torch.cuda.Stream()):
+            prob = fos.prepare(A, b)
+            res = []
+            for kw in (dict(), dict(adaptive_restart=True, restart_threshold=1.0)):
+                st = _core.Fista(prob); st.reset(tau, 0.5, 0.1, **kw)
+                for _ in range(4):
+                    st.run(25)
+                res.append(st.x_tensor().clone())
+            x64 = res[0].double()
+            o = torch.zeros(prob.n_dev + 1, dtype=torch.float64, device="cuda")
+            _lib.check(prob.lib.fos_gemv_pair_dd(prob.h, _core.ptr(x64), 0.1, _core.ptr(o)))
+            res.append(o.clone())
+            torch.cuda.current_stream().synchronize()
+            out[i] = res
+
+    seq, par = {}, {}
+    for i in range(len(shapes)):
+        work(i, seq)
+    errors = []
+
+    def guarded(i):
+        try:
+            work(i, par)
+        except Exception as exc:        # surfaces in the main thread
+            errors.append((i, repr(exc)))
+
+    for _ in range(3):
+        par.clear()
+        threads = [threading.Thread(target=guarded, args=(i,)) for i in range(len(shapes))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        for i in range(len(shapes)):
+            for a, c in zip(seq[i], par[i]):
+                assert torch.equal(a, c), (i, shapes[i])
