@@ -75,3 +75,25 @@ def test_missing_library_is_loud(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.FosError):
         _lib.load()
+
+
+def test_solvers_refuse_to_run_without_a_gpu():
+    """No CPU fallback anywhere on the product path: on a box without a ROCm device every entry point of the Python
+    boundary raises FosError (it never computes on the host, never touches the oracle)."""
+    import numpy as np
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    import fastoptsolver_amd as fos
+    from fastoptsolver_amd import _lib
+    A, b = np.ones((8, 4)), np.ones(8)
+    calls = [lambda: fos.fista(A, b, "lasso", 0.1, 0.0, max_iter=2),
+             lambda: fos.fista_delta(A, b, "lasso", 0.1, 0.0, 3.0, max_iter=2),
+             lambda: fos.estimate_lipschitz(A),
+             lambda: fos.LBFGSSolver("ridge", 0.0, 1.0).fit(A, b),
+             lambda: fos.compute_objective(np.zeros(4), A, b, "lasso", 0.1, 0.0),
+             lambda: fos.fista_path(A, b, [(0.1, 0.0), (0.2, 0.0)], max_iter=2),
+             lambda: fos.prepare(A, b)]
+    for call in calls:
+        with pytest.raises(_lib.FosError):
+            call()
