@@ -308,16 +308,20 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
       if constexpr (DUAL) part[R + r] = wave_sum(acc2 + acc3);
     }
     const int pb = (int)(step & 1);
-    if (lane == 0) {
+    if constexpr (NW > 1) {                    // (one wave per row: the wave sum IS the row dot - no LDS trip, no barrier)
+      if (lane == 0) {
 #pragma unroll
-      for (int r = 0; r < R * NV; ++r) red[pb][r][wave] = part[r];
+        for (int r = 0; r < R * NV; ++r) red[pb][r][wave] = part[r];
+      }
+      __syncthreads();
     }
-    __syncthreads();
     ACC res[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       ACC s = (ACC)0;
-      if constexpr (KEEPCVT && NW >= 8) {      // one partial per lane + the DPP ladder: 2 VGPRs instead of 2*NW
+      if constexpr (NW == 1) {
+        s = part[r];
+      } else if constexpr (KEEPCVT && NW >= 8) {      // one partial per lane + the DPP ladder: 2 VGPRs instead of 2*NW
         s = wave_sum(lane < NW ? red[pb][r][lane] : (ACC)0);
       } else {
 #pragma unroll
@@ -338,6 +342,8 @@ __global__ __launch_bounds__(THREADS, MINW) void gemv_pair_kernel(
       }
       if constexpr (DUAL) {
         ACC s2 = (ACC)0;
+        if constexpr (NW == 1) s2 = part[R + r];
+        else
 #pragma unroll
         for (int w = 0; w < NW; ++w) s2 += red[pb][R + r][w];
         if (row < row_hi) { s2 -= bi; rr2 += (double)s2 * (double)s2; }
