@@ -24,6 +24,8 @@ for n in widths:
         A = A.to(torch.bfloat16)
     b = torch.randn(m, device="cuda", generator=g)
     prob = fos.prepare(A, b)
+    if os.environ.get("FOS_BENCH_IL"):
+        prob.replan(interleave=os.environ["FOS_BENCH_IL"] == "1")
     if dd:
         from fastoptsolver_amd import _lib
         x64 = torch.randn(n, dtype=torch.float64, device="cuda")
