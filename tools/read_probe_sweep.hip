@@ -70,14 +70,15 @@ int main(int argc, char** argv) {
       V(512, 16, false, true), V(1024, 4, false, true), V(1024, 8, false, true), V(512, 8, false, false), V(1024, 4, false, false),
       V(256, 8, true, true),   V(512, 4, true, true),   V(512, 8, true, true),   V(1024, 4, true, true), V(1024, 8, true, true),
       V(512, 8, true, false),  V(1024, 4, true, false), V(1024, 8, true, false),
+      V(64, 8, true, true),    V(64, 16, true, true),   V(64, 8, false, true),   // single-wave workgroups (narrow-row geometries)
   };
   printf("device %s, %d CUs, buffer %.2f GiB\n", prop.name, ncu, bytes / 1073741824.0);
   const size_t n16 = bytes / 16;
   const int iters = std::max(3, (int)(4e10 / bytes));
   for (int round = 0; round < 2; ++round)
     for (auto& v : vs)
-      for (int per_cu : {1, 2, 4, 8}) {
-        if (v.threads * per_cu > 2048) continue;
+      for (int per_cu : {1, 2, 4, 8, 16, 32}) {
+        if (v.threads * per_cu > 2048 || (per_cu > 8 && v.threads > 64)) continue;
         const int grid = ncu * per_cu;
         v.fn<<<grid, v.threads>>>(buf, n16, sink);
         CK(hipDeviceSynchronize());
