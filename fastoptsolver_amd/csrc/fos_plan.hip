@@ -278,7 +278,13 @@ void plan_fused(fos_problem* p, const MenuEntry* e, int nwg_hint) {
   // 64-96 KiB of rows in flight per CU; two for the 256-thread geometries with 1-2 chunks per thread (1048576 x 1024:
   // 67 % -> 88 % of the roofline - one such workgroup has 32 KiB in flight, below HBM latency x bandwidth per CU);
   // 16 single-wave workgroups for the one-wave-per-row geometries.
-  const int per_cu = e->threads >= 512 ? 1 : e->threads == 256 ? (e->k <= 2 ? 2 : 1) : 1024 / e->threads;
+  // One-wave-per-row geometries (64 threads), round 3: FOUR workgroups per CU - a wave per SIMD - not sixteen.  Whole step at
+  // ~2 GiB (tools/wg_sweep.py, profiles/r03_wg_sweep.txt): 2097152 x 256 77.5 -> 86.1 % of 8 TB/s, 1048576 x 512 75.6 -> 84.3 %,
+  // 1398016 x 320 71.2 -> 82.3 %; the A pass itself is 5-8 % faster with fewer, longer streams, and the update kernel sums a
+  // quarter of the slabs (200000 x 256: its share fell from 26 to 8 us of a 63 -> 44 us iteration).  Rows that leave more than
+  // a fifth of the wave's lanes without a chunk (n <= 204 on the one-chunk geometry) need eight: 2796032 x 160 74.3 -> 79.9 %.
+  const bool sparse_wave = e->threads == 64 && e->k == 1 && p->n * 5 <= 4 * 64 * (int64_t)epc_of(p->dtype);
+  const int per_cu = e->threads >= 512 ? 1 : e->threads == 256 ? (e->k <= 2 ? 2 : 1) : (sparse_wave ? 8 : 4);
   int nwg = nwg_hint > 0 ? nwg_hint : p->ncu * per_cu;
   // at least 2 row steps and 32 KiB of rows per workgroup: below that the slab (one row of n floats per workgroup) and the
   // slab sums rival the rows they cover (20000 x 256: 26 -> 17.5 us per iteration at 32 rows, 4096 x 512 best at 16 rows,
@@ -298,10 +304,16 @@ void plan_tall(fos_problem* p, const MenuEntry* e) {
   p->tall = true;
   p->slab_stride = fos::tall_slab_stride((int)p->n);
   p->vec4 = true;                    // padded slab rows: the float4 epilogues serve ragged n as well
-  // 4 workgroups per CU; 8 for the chunk-per-lane form (17-40 VGPRs: 8 workgroups are resident, each with 4 KiB per
-  // wave in flight) - profiles/r02_sweep_wgs.log
-  const int per_cu = e->k > 0 ? 8 : 4;
-  int64_t nwg = std::max<int64_t>(1, std::min<int64_t>(per_cu * (int64_t)p->ncu, p->m / (4 * fos::TL_THREADS)));
+  // 4 workgroups per CU for the row-per-thread forms (profiles/r02_sweep_wgs.log)
+  // (round 3, whole-step sweep tools/wg_sweep.py: the chunk-per-lane form wants 2 workgroups per CU when its rows fill the
+  //  lanes - 2000000 x 64: 102.7 -> 89.6 us, 4000000 x 32: 93.3 -> 89.5 us - and 4 when a fifth or more of them idle -
+  //  2000000 x 96: 155.6 -> 148.3 us; eight only made the update kernel sum more slabs.  It also keeps its workgroup count
+  //  up on shorter matrices - 384 rows per workgroup are enough: 300000 x 64 31.6 -> 25.7 us, 200000 x 100 43.7 -> 30.0 us.)
+  const int64_t lane_cols = (int64_t)e->k * epc_of(p->dtype);            // k = lanes per row of the chunk-per-lane entries
+  // (a row per 32 lanes, 8 rows per workgroup step: three - 4194304 x 128: 76.1 % at two, 80.0 % at three or four)
+  const int per_cu = e->k > 0 ? (p->n * 5 <= 4 * lane_cols ? 4 : (e->k >= 32 ? 3 : 2)) : 4;
+  const int64_t rows_min = e->k > 0 ? 384 : 4 * fos::TL_THREADS;
+  int64_t nwg = std::max<int64_t>(1, std::min<int64_t>(per_cu * (int64_t)p->ncu, p->m / rows_min));
   p->rows_per_wg = ((p->m + nwg - 1) / nwg + 3) / 4 * 4;     // a multiple of 4 rows: 16-byte aligned block starts (staged copy)
   p->nwg = (int)((p->m + p->rows_per_wg - 1) / p->rows_per_wg);
   p->nslabs = p->nwg;
@@ -751,7 +763,9 @@ int ensure_dd(fos_problem* p) {
       // fp64 form: two workgroups per CU for the 256-thread geometries (they hold 2 waves per SIMD at most 256 VGPRs
       // each); four for the one-chunk geometry (76 VGPRs; 1048576 x 1024: 723 -> 660 us = 81 % of 8 TB/s, tools/dd_bench;
       // the two-chunk geometry is best at two: 524288 x 2048 87.5 % against 82 %)
-      int nwg = p->ncu * (e->threads >= 512 ? 1 : e->threads == 256 ? (e->k == 1 ? 4 : 2) : 1024 / e->threads);
+      // (single-wave geometries: 4 per CU, 8 when the rows leave a fifth of the lanes idle - as in plan_fused)
+      const bool sparse_wave = e->threads == 64 && e->k == 1 && p->n * 5 <= 4 * 64 * (int64_t)epc_of(p->dtype);
+      int nwg = p->ncu * (e->threads >= 512 ? 1 : e->threads == 256 ? (e->k == 1 ? 4 : 2) : (sparse_wave ? 8 : 4));
       const int64_t row_bytes = p->n * (p->dtype == FOS_F32 ? 4 : 2);
       const int64_t min_rows = std::max<int64_t>(2 * (int64_t)e->r, (65536 + row_bytes - 1) / row_bytes);   // fp64 slabs
       if (p->m < (int64_t)nwg * min_rows) nwg = (int)std::max<int64_t>(1, p->m / min_rows);
