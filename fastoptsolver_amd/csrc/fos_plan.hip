@@ -284,7 +284,12 @@ void plan_fused(fos_problem* p, const MenuEntry* e, int nwg_hint) {
   // quarter of the slabs (200000 x 256: its share fell from 26 to 8 us of a 63 -> 44 us iteration).  Rows that leave more than
   // a fifth of the wave's lanes without a chunk (n <= 204 on the one-chunk geometry) need eight: 2796032 x 160 74.3 -> 79.9 %.
   const bool sparse_wave = e->threads == 64 && e->k == 1 && p->n * 5 <= 4 * 64 * (int64_t)epc_of(p->dtype);
-  const int per_cu = e->threads >= 512 ? 1 : e->threads == 256 ? (e->k <= 2 ? 2 : 1) : (sparse_wave ? 8 : 4);
+  // 256 threads: two per CU up to two chunks per thread, one above; a row that leaves lanes without a chunk wants one more -
+  // 838656 x 640 on 256 x 1 (62 % filled): 77.5 -> 82.4 % with three, 209664 x 2560 on 256 x 3 (83 %): 82.3 -> 86.1 % with two
+  // (full rows on 256 x 3: 88 % with one, 82 % with two)
+  const int64_t cap256 = 256 * (int64_t)e->k * epc_of(p->dtype);
+  const bool sparse_256 = e->threads == 256 && ((e->k == 1 && p->n * 10 <= 7 * cap256) || (e->k == 3 && p->n * 10 <= 9 * cap256));
+  const int per_cu = e->threads >= 512 ? 1 : e->threads == 256 ? (e->k <= 2 ? 2 : 1) + (sparse_256 ? 1 : 0) : (sparse_wave ? 8 : 4);
   int nwg = nwg_hint > 0 ? nwg_hint : p->ncu * per_cu;
   // at least 2 row steps and 32 KiB of rows per workgroup: below that the slab (one row of n floats per workgroup) and the
   // slab sums rival the rows they cover (20000 x 256: 26 -> 17.5 us per iteration at 32 rows, 4096 x 512 best at 16 rows,

@@ -6,14 +6,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fastoptsolver_amd as fos
 from fastoptsolver_amd import _core, _lib
 torch.cuda.set_device(0)
-shapes = [(4194304, 128), (5592320, 96), (7456512, 72), (8000000, 64), (16000000, 32), (12000000, 40)] if "big" in sys.argv else [(4000000, 32), (2000000, 64), (1000000, 128), (2000000, 96), (8000000, 5), (4000000, 16), (32000000, 5), (300000, 64), (200000, 100), (500000, 8),
+shapes = [(838656, 640), (698880, 768), (419328, 1280), (349440, 1536), (209664, 2560), (149760, 3584), (74752, 7168), (37376, 14336)] if "mid" in sys.argv else [(4194304, 128), (5592320, 96), (7456512, 72), (8000000, 64), (16000000, 32), (12000000, 40)] if "big" in sys.argv else [(4000000, 32), (2000000, 64), (1000000, 128), (2000000, 96), (8000000, 5), (4000000, 16), (32000000, 5), (300000, 64), (200000, 100), (500000, 8),
           (2796032, 160), (2097152, 224), (1398016, 320), (1398016, 448)]
 for m, n in shapes:
     A = torch.randn(m, n, device="cuda"); b = torch.randn(m, device="cuda")
     prob = fos.prepare(A, b)
     pl = prob.plan()
     base = pl["workgroups"]
-    cands = sorted(set([256, 512, 768, 1024, 1536, 2048, 3072, 4096, base]))
+    cands = sorted(set([256, 512, 768, 1024, 1536, 2048, 3072, 4096, base])) if 'mid' not in sys.argv else sorted(set([128, 256, 384, 512, 768, 1024, 2048, base]))
     for wg in cands:
         try:
             prob.tune(pl["threads"], pl["chunks"], pl["rows"], wg)
