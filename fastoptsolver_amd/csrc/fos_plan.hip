@@ -64,7 +64,8 @@ const DdEntry kDdMenu[] = {
     DD_ENTRY_IL(FOS_F32, float, 256, 4, 1, false), DD_ENTRY_IL(FOS_F32, float, 512, 3, 1, false),
     DD_ENTRY3_IL(FOS_F32, float, 512, 4, 1, false), DD_ENTRY_IL(FOS_F32, float, 512, 5, 1, false),
     DD_ENTRY_IL(FOS_F32, float, 512, 8, 1, true),          // (512 x 6 with y in LDS measured 3 % behind this one at 12288 columns)
-    DD_ENTRY(FOS_BF16, fos::bf16_t, 64, 1, 2, false), DD_ENTRY(FOS_BF16, fos::bf16_t, 256, 1, 2, false),
+    DD_ENTRY(FOS_BF16, fos::bf16_t, 64, 1, 2, false), DD_ENTRY(FOS_BF16, fos::bf16_t, 64, 2, 2, false),
+    DD_ENTRY(FOS_BF16, fos::bf16_t, 256, 1, 2, false),
     DD_ENTRY(FOS_BF16, fos::bf16_t, 256, 2, 1, false), DD_ENTRY_IL(FOS_BF16, fos::bf16_t, 256, 3, 1, false),
     // bf16 rows of 4 chunks per thread: the pass is VALU-bound (56 VALU instructions per 16-byte chunk: unpack + convert
     // for the dot, AGAIN for the gradient update, 16 v_fma_f64), so these keep the converted tile across the barrier
@@ -128,7 +129,7 @@ const MenuEntry kMenu[] = {
     ENTRY_NB_IL(FOS_F32, float, 512, 5, 1, 2, 3),   ENTRY_DRAIN(FOS_F32, float, 1024, 3, 1, 4, 512, 6, 2),
     ENTRY_NB_IL(FOS_F32, float, 512, 7, 1, 2, 2),   ENTRY_DRAIN(FOS_F32, float, 1024, 4, 1, 4, 512, 8, 2),
     ENTRY_D(FOS_F32, float, 512, 8, 1, 2),  ENTRY(FOS_F32, float, 1024, 2, 2, 4),
-    ENTRY(FOS_BF16, fos::bf16_t, 64, 1, 4, 2),                      // one wave per row: up to 512 bf16 columns
+    ENTRY(FOS_BF16, fos::bf16_t, 64, 1, 4, 2), ENTRY(FOS_BF16, fos::bf16_t, 64, 2, 4, 2),   // one wave per row: up to 512 / 1024 bf16 columns
     ENTRY(FOS_BF16, fos::bf16_t, 256, 1, 4, 2), ENTRY(FOS_BF16, fos::bf16_t, 256, 2, 2, 2),
     ENTRY_NB_IL(FOS_BF16, fos::bf16_t, 256, 3, 1, 2, 3), ENTRY_NB_IL(FOS_BF16, fos::bf16_t, 256, 4, 1, 2, 3),
     ENTRY_IL_ND(FOS_BF16, fos::bf16_t, 256, 5, 1, 2),
@@ -142,6 +143,10 @@ const MenuEntry* find_entry(int dtype, int threads, int k, int r) {
   return nullptr;
 }
 int epc_of(int dtype) { return dtype == FOS_F32 ? 4 : 8; }
+// chunk-per-lane rows: up to 128 columns - 32 lanes per row in fp32, 16 in bf16 (a bf16 row per 32 lanes, 129..256 columns,
+// measured no better than the half-filled one-wave-per-row geometry: the pass converts and accumulates in fp64 and is
+// instruction-bound on 2-byte elements - 2097152 x 256 bf16: 58.5 % against 61.0 %)
+int64_t tlr_max_n(int /*dtype*/) { return fos::TLR_MAX_N; }
 const MenuEntry* default_entry(int dtype, int64_t n) {
   for (const auto& e : kMenu)
     if (e.dtype == dtype && (int64_t)e.threads * e.k * epc_of(dtype) >= n) return &e;
@@ -730,7 +735,7 @@ void apply_plan(fos_problem* p, unsigned flags) {
   const int epc = epc_of(p->dtype);
   const bool vec_ok = (n % epc == 0) && (p->lda % epc == 0) && ((reinterpret_cast<uintptr_t>(p->A) & 15u) == 0);
   const MenuEntry* e = vec_ok ? default_entry(p->dtype, n) : nullptr;
-  if ((n <= fos::TL_MAX_N || (n <= fos::TLR_MAX_N && vec_ok)) && !(flags & FOS_PLAN_NO_TALL))
+  if ((n <= fos::TL_MAX_N || (n <= tlr_max_n(p->dtype) && vec_ok)) && !(flags & FOS_PLAN_NO_TALL))
     plan_tall(p, tall_entry(p->dtype, n, p->lda, p->A));
   else if (e) plan_fused(p, e, 0);
   else if (vec_ok && n <= fos::WD_MAX_N && !(flags & FOS_PLAN_NO_WIDE)) plan_fused(p, wide_entry(p->dtype), 0);
@@ -915,8 +920,8 @@ int fos_problem_set_comm_cols(fos_problem* p, fos_comm* c) {
   if (!p || !c) return fail(FOS_ERR_ARG, "fos_problem_set_comm_cols: null");
   const int epc = epc_of(p->dtype);
   const bool vec_ok = (p->n % epc == 0) && (p->lda % epc == 0) && ((reinterpret_cast<uintptr_t>(p->A) & 15u) == 0);
-  if (!vec_ok || p->n <= fos::TLR_MAX_N)
-    return fail(FOS_ERR_UNSUPPORTED, "fos_problem_set_comm_cols: needs the streaming layout (aligned, n > 128 per rank)");
+  if (!vec_ok || p->n <= tlr_max_n(p->dtype))
+    return fail(FOS_ERR_UNSUPPORTED, "fos_problem_set_comm_cols: needs the streaming layout (aligned, more than 32 chunks of 16 bytes per row and rank)");
   // the two-phase column-block plan, whatever the width: r = sum_p A_p y_p - b is exchanged between the phases
   void* drop[] = {p->slabs, p->rr_part, p->rr2_part};
   for (void* q : drop)

@@ -762,7 +762,7 @@ def test_wide_rows_bf16_and_sharded_column_blocks(fos):
 @pytest.mark.parametrize("kind,m,n,geo", [
     ("f32", 300, 2560, (256, 3)), ("f32", 257, 3072, (256, 3)), ("f32", 515, 5000, (256, 5)), ("f32", 260, 6144, (512, 3)),
     ("f32", 300, 10000, (512, 5)), ("f32", 259, 12288, (1024, 3)), ("f32", 131, 12292, (512, 7)), ("f32", 140, 14336, (512, 7)),
-    ("bf16", 300, 5120, (256, 3)), ("bf16", 257, 6144, (256, 3)), ("bf16", 300, 12288, (512, 3)), ("bf16", 260, 10000, (256, 5)),
+    ("bf16", 3000, 768, (64, 2)), ("bf16", 2000, 1024, (64, 2)), ("bf16", 300, 5120, (256, 3)), ("bf16", 257, 6144, (256, 3)), ("bf16", 300, 12288, (512, 3)), ("bf16", 260, 10000, (256, 5)),
     ("bf16", 150, 20000, (512, 5)), ("bf16", 130, 24576, (512, 6)), ("bf16", 131, 24584, (512, 8)), ("bf16", 200, 32768, (512, 8))])
 def test_three_chunk_geometries_and_bf16_wide_rows(fos, kind, m, n, geo):
     """Round 3: widths between the powers of two get geometries of three, five or seven chunks per thread (a chunk beyond n is
