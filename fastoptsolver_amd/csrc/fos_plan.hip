@@ -143,10 +143,8 @@ const MenuEntry* find_entry(int dtype, int threads, int k, int r) {
   return nullptr;
 }
 int epc_of(int dtype) { return dtype == FOS_F32 ? 4 : 8; }
-// chunk-per-lane rows: up to 128 columns - 32 lanes per row in fp32, 16 in bf16 (a bf16 row per 32 lanes, 129..256 columns,
-// measured no better than the half-filled one-wave-per-row geometry: the pass converts and accumulates in fp64 and is
-// instruction-bound on 2-byte elements - 2097152 x 256 bf16: 58.5 % against 61.0 %)
-int64_t tlr_max_n(int /*dtype*/) { return fos::TLR_MAX_N; }
+// chunk-per-lane rows: up to 32 lanes per row - 128 fp32 / 256 bf16 columns
+int64_t tlr_max_n(int dtype) { return 32 * (int64_t)epc_of(dtype); }
 const MenuEntry* default_entry(int dtype, int64_t n) {
   for (const auto& e : kMenu)
     if (e.dtype == dtype && (int64_t)e.threads * e.k * epc_of(dtype) >= n) return &e;
@@ -207,7 +205,9 @@ void tallq_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, 
 template <typename T, int LPR, bool WITH_G, bool DUAL>
 void tallr_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, float* slabs,
                   double* rr_part, double* rr2_part, int nwg, hipStream_t st) {
-  hipLaunchKernelGGL((fos::gemv_tall_rows_kernel<T, LPR, WITH_G, DUAL>), dim3(nwg), dim3(fos::TL_THREADS), 0, st,
+  // fp32 pass: bf16 storage accumulates in fp32 like its streaming siblings, fp32 storage in fp64 (gemv_tall.hpp "AT")
+  using AT = typename std::conditional<std::is_same<T, float>::value, double, float>::type;
+  hipLaunchKernelGGL((fos::gemv_tall_rows_kernel<T, LPR, WITH_G, DUAL, float, AT>), dim3(nwg), dim3(fos::TL_THREADS), 0, st,
                      reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part, rr2_part);
 }
 template <typename T, int LPR>
@@ -222,7 +222,7 @@ void tallr_launch_dd(const void* A, int64_t lda, const float* b, int64_t m, int 
     tallr_launch<T, LPR, true, true>, tallr_launch_dd<T, LPR> }
 // (a row per 4 lanes - up to 4 chunks - measured slower than the row-per-thread form and is not instantiated)
 const MenuEntry kTallRowsF32[3] = {TALLR(FOS_F32, float, 8), TALLR(FOS_F32, float, 16), TALLR(FOS_F32, float, 32)};
-const MenuEntry kTallRowsBf16[2] = {TALLR(FOS_BF16, fos::bf16_t, 8), TALLR(FOS_BF16, fos::bf16_t, 16)};
+const MenuEntry kTallRowsBf16[3] = {TALLR(FOS_BF16, fos::bf16_t, 8), TALLR(FOS_BF16, fos::bf16_t, 16), TALLR(FOS_BF16, fos::bf16_t, 32)};
 #undef TALLR
 // 33..64 columns: a row per quad of lanes (gemv_tall_quad_kernel)
 #define TALLQ(DT, T, VEC) \
@@ -255,7 +255,7 @@ const MenuEntry* tall_entry(int dtype, int64_t n, int64_t lda, const void* A) {
     // a 72-column row left 46 of 64 lanes re-reading chunk 0 (53 % of 8 TB/s at 7456512 x 72; tools/bench_widths.py narrow)
     const int chunks = (int)(n / epc);
     if (dtype == FOS_F32) return &kTallRowsF32[chunks <= 8 ? 0 : chunks <= 16 ? 1 : 2];
-    return &kTallRowsBf16[chunks <= 8 ? 0 : 1];
+    return &kTallRowsBf16[chunks <= 8 ? 0 : chunks <= 16 ? 1 : 2];       // bf16: up to 256 columns
   }
   const int idx = n <= 8 ? 0 : n <= 16 ? 1 : n <= 32 ? 2 : 3;
   const bool contiguous = (lda == n);

@@ -330,7 +330,22 @@ __device__ inline double lanes_sum(double v) {
   return v;                                                //  both ways on this ISA: one ds_bpermute pair per row step)
 }
 
-template <typename T, int LPR, bool WITH_G, bool DUAL, typename ST = float>
+template <int LPR>
+__device__ inline float lanes_sum(float v) {
+  static_assert(LPR == 4 || LPR == 8 || LPR == 16 || LPR == 32, "LPR");
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+  if constexpr (LPR >= 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
+  if constexpr (LPR >= 16) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
+  if constexpr (LPR >= 32) v += __shfl_xor(v, 16);
+  return v;
+}
+
+// AT: accumulator type of the row dot and the gradient slice.  double for fp32 storage (the ill-conditioned regression data
+// this family exists for) and for every fp64 pass; float for the fp32 pass over bf16 storage (round 3: eight 2-byte
+// elements per chunk through fp64 conversion and accumulation made that pass instruction-bound at 42-54 % of the roofline;
+// its streaming siblings accumulate in fp32 as well).  ||r||^2 stays fp64.
+template <typename T, int LPR, bool WITH_G, bool DUAL, typename ST = float, typename AT = double>
 __global__ __launch_bounds__(TL_THREADS) void gemv_tall_rows_kernel(const T* __restrict__ A, int64_t lda,
                                                                    const float* __restrict__ b, int64_t m, int n, YSource ys,
                                                                    int64_t rows_per_wg, ST* __restrict__ slabs,
@@ -340,7 +355,7 @@ __global__ __launch_bounds__(TL_THREADS) void gemv_tall_rows_kernel(const T* __r
   constexpr int RPS = TL_THREADS / LPR;         // rows per step of the workgroup
   constexpr int U = 4;                          // row steps in flight per lane (8 measured the same: r02_sweep_wgs)
   constexpr int NW = TL_THREADS / 64;
-  __shared__ double gred[WITH_G ? TL_THREADS : 1][EPL];
+  __shared__ AT gred[WITH_G ? TL_THREADS : 1][EPL];
   __shared__ double red[NW][2];
   if (ys.stopped != nullptr && *ys.stopped != 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -348,12 +363,12 @@ __global__ __launch_bounds__(TL_THREADS) void gemv_tall_rows_kernel(const T* __r
   const int cbase = sub * EPL;
   const bool live = cbase < n;                  // n % EPL == 0: a chunk is inside the row or outside it entirely
   const double beta = source_beta(ys);
-  double yv[EPL], xv[DUAL ? EPL : 1], g[WITH_G ? EPL : 1];
+  AT yv[EPL], xv[DUAL ? EPL : 1], g[WITH_G ? EPL : 1];
 #pragma unroll
   for (int e = 0; e < EPL; ++e) {
-    yv[e] = live ? source_y(ys, cbase + e, beta) : 0.0;
-    if constexpr (DUAL) xv[e] = live ? ys.x_cur[cbase + e] : 0.0;
-    if constexpr (WITH_G) g[e] = 0.0;
+    yv[e] = live ? (AT)source_y(ys, cbase + e, beta) : (AT)0;
+    if constexpr (DUAL) xv[e] = live ? (AT)ys.x_cur[cbase + e] : (AT)0;
+    if constexpr (WITH_G) g[e] = (AT)0;
   }
   double rr = 0.0, rr2 = 0.0;
   const int64_t row_lo = (int64_t)blockIdx.x * rows_per_wg;
@@ -381,24 +396,24 @@ __global__ __launch_bounds__(TL_THREADS) void gemv_tall_rows_kernel(const T* __r
       const bool in = (row0 + u * RPS + rslot < row_hi) && live;
       float a[EPL];
       Tr::unpack(raw[u], a);
-      double acc = 0.0, acc2 = 0.0;
+      AT acc = (AT)0, acc2 = (AT)0;
 #pragma unroll
       for (int e = 0; e < EPL; ++e) {
         a[e] = in ? a[e] : 0.f;                  // masked rows / lanes: a = 0 -> no contribution to the dot or to g
-        acc = fma((double)a[e], yv[e], acc);
-        if constexpr (DUAL) acc2 = fma((double)a[e], xv[e], acc2);
+        acc = fma((AT)a[e], yv[e], acc);
+        if constexpr (DUAL) acc2 = fma((AT)a[e], xv[e], acc2);
       }
       const bool row_in = row0 + u * RPS + rslot < row_hi;
-      const double bv = (row_in && b != nullptr) ? (double)bi[u] : 0.0;
+      const AT bv = (row_in && b != nullptr) ? (AT)bi[u] : (AT)0;
       acc = lanes_sum<LPR>(acc) - bv;
-      if (sub == 0 && row_in) rr += acc * acc;
+      if (sub == 0 && row_in) rr += (double)acc * (double)acc;
       if constexpr (DUAL) {
         acc2 = lanes_sum<LPR>(acc2) - bv;
-        if (sub == 0 && row_in) rr2 += acc2 * acc2;
+        if (sub == 0 && row_in) rr2 += (double)acc2 * (double)acc2;
       }
       if constexpr (WITH_G) {
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) g[e] = fma((double)a[e], acc, g[e]);
+        for (int e = 0; e < EPL; ++e) g[e] = fma((AT)a[e], acc, g[e]);
       }
     }
   };
@@ -421,7 +436,7 @@ __global__ __launch_bounds__(TL_THREADS) void gemv_tall_rows_kernel(const T* __r
     if (tid < LPR * EPL) {                       // column tid: held by the lanes with sub == tid / EPL, one per row slot
       const int sb = tid / EPL, e = tid % EPL;
       double tot = 0.0;
-      for (int k = 0; k < RPS; ++k) tot += gred[k * LPR + sb][e];
+      for (int k = 0; k < RPS; ++k) tot += (double)gred[k * LPR + sb][e];
       if (tid < sstride) slabs[(int64_t)blockIdx.x * sstride + tid] = tid < n ? (ST)tot : (ST)0;
     }
   }

@@ -1310,7 +1310,8 @@ def test_resident_loop_with_bf16_storage(fos):
                                       (7000, 48, "strided"), (9000, 16, "bf16"), (8000, 40, "bf16"), (5003, 64, "bf16"),
                                       # round 3: 65..128 columns, a row per 32 lanes (fp32) / 16 lanes (bf16)
                                       (30001, 68, "f32"), (20000, 100, "f32"), (9000, 128, "f32"), (3, 72, "f32"),
-                                      (7001, 120, "strided"), (8000, 72, "bf16"), (5003, 128, "bf16")])
+                                      (7001, 120, "strided"), (8000, 72, "bf16"), (5003, 128, "bf16"),
+                                      (6000, 192, "bf16"), (4001, 256, "bf16")])           # bf16: 32 lanes per row up to 256 columns
 def test_tall_skinny_gemv_pair(fos, m, n, kind):
     rng = np.random.default_rng(m + n)
     A = rng.standard_normal((m, n)).astype(np.float32)
