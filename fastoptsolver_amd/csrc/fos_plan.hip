@@ -206,7 +206,8 @@ template <typename T, int LPR, bool WITH_G, bool DUAL>
 void tallr_launch(const void* A, int64_t lda, const float* b, int64_t m, int n, YSource ys, int64_t rpw, float* slabs,
                   double* rr_part, double* rr2_part, int nwg, hipStream_t st) {
   // fp32 pass: bf16 storage accumulates in fp32 like its streaming siblings, fp32 storage in fp64 (gemv_tall.hpp "AT")
-  using AT = typename std::conditional<std::is_same<T, float>::value, double, float>::type;
+  // (fp32 rows of 65..128 columns - 32 lanes per row - ran on the fp32-accumulating streaming kernel until round 3: fp32 too)
+  using AT = typename std::conditional<std::is_same<T, float>::value && (LPR < 32), double, float>::type;
   hipLaunchKernelGGL((fos::gemv_tall_rows_kernel<T, LPR, WITH_G, DUAL, float, AT>), dim3(nwg), dim3(fos::TL_THREADS), 0, st,
                      reinterpret_cast<const T*>(A), lda, b, m, n, ys, rpw, slabs, rr_part, rr2_part);
 }
