@@ -139,6 +139,15 @@ __device__ inline f32x4 reduce_slab_block(const float* __restrict__ slabs, int n
   if (col < n) {
     const float* p = slabs + col;
     int s = grp;
+    // eight loads in flight first (round 3; sixteen measured the same): every trip is a round trip to the memory side (the slabs were written by other
+    // XCDs), and a narrow plan's 1024 slabs were 16 dependent trips of four - same order of additions, same sums
+    for (; s + 7 * ng < nslabs; s += 8 * ng) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (int64_t)(s + u * ng) * stride);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
     for (; s + 3 * ng < nslabs; s += 4 * ng) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(p + (int64_t)s * stride);
       const f32x4 b = *reinterpret_cast<const f32x4*>(p + (int64_t)(s + ng) * stride);
