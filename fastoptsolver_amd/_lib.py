@@ -51,6 +51,7 @@ SIGNATURES = {
     "fos_problem_destroy": (_i32, [_vp]),
     "fos_problem_plan": (_i32, [_vp, C.POINTER(C.c_int32)]),
     "fos_problem_tune": (_i32, [_vp, _i32, _i32, _i32, _i32]),
+    "fos_problem_tune_dd": (_i32, [_vp, _i32]),
     "fos_problem_set_gbuf": (_i32, [_vp, _vp]),
     "fos_problem_set_stream": (_i32, [_vp, _vp]),
     "fos_problem_replan": (_i32, [_vp, C.c_uint]),

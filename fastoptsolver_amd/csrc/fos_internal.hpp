@@ -138,6 +138,7 @@ struct fos_problem {
   // fp64-accumulating pass (fos_gemv_pair_dd): own geometry and fp64 slabs, allocated on first use
   const DdEntry* dd_entry = nullptr;
   int dd_nwg = 0;
+  int dd_nwg_hint = 0;               // fos_problem_tune_dd: workgroups of the streaming fp64 pass (0 = planner)
   int64_t dd_rows_per_wg = 0;
   double* slabs_dd = nullptr;
   double* rr_dd = nullptr;

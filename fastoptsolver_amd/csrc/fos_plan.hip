@@ -59,6 +59,7 @@ void fused_launch_dd(const void* A, int64_t lda, const float* b, int64_t m, int 
 #define DD_ENTRY3_IL(DT, T, TH, K, R, YL) { DT, TH, K, R, fused_launch_dd<T, TH, K, R, 2, YL, 3>, fused_launch_dd<T, TH, K, R, 2, YL, 3, true> }
 const DdEntry kDdMenu[] = {
     DD_ENTRY(FOS_F32, float, 64, 1, 4, false), DD_ENTRY(FOS_F32, float, 64, 2, 2, false),
+    DD_ENTRY(FOS_F32, float, 64, 3, 2, false),             // 513..768 columns (on 256 x 1 at 62-75 % filled: 58-66 % of 8 TB/s)
     DD_ENTRY(FOS_F32, float, 256, 1, 2, false), DD_ENTRY(FOS_F32, float, 256, 2, 2, false),
     DD_ENTRY(FOS_F32, float, 256, 3, 1, false),            // (3, 5 chunks: widths between the powers of two, as in kMenu: +3-5 %)
     DD_ENTRY_IL(FOS_F32, float, 256, 4, 1, false), DD_ENTRY_IL(FOS_F32, float, 512, 3, 1, false),
@@ -774,11 +775,20 @@ int ensure_dd(fos_problem* p) {
       // fp64 form: two workgroups per CU for the 256-thread geometries (they hold 2 waves per SIMD at most 256 VGPRs
       // each); four for the one-chunk geometry (76 VGPRs; 1048576 x 1024: 723 -> 660 us = 81 % of 8 TB/s, tools/dd_bench;
       // the two-chunk geometry is best at two: 524288 x 2048 87.5 % against 82 %)
-      // (single-wave geometries: 4 per CU, 8 when the rows leave a fifth of the lanes idle - as in plan_fused)
-      const bool sparse_wave = e->threads == 64 && e->k == 1 && p->n * 5 <= 4 * 64 * (int64_t)epc_of(p->dtype);
-      int nwg = p->ncu * (e->threads >= 512 ? 1 : e->threads == 256 ? (e->k == 1 ? 4 : 2) : (sparse_wave ? 8 : 4));
+      // Swept on the whole fg (pass + fp64 slab sum, tools/wg_sweep_dd.py, profiles/r03_wg_sweep.txt): the single-wave
+      // geometries want eight per CU (2097152 x 256: 378 -> 348 us, 1677568 x 320: 420 -> 357 us) except full two-chunk rows
+      // (1048576 x 512: four, 308 us against 336); two-chunk 256-thread rows that leave 30 % of the lanes without a chunk four
+      // instead of two (419328 x 1280: 403 -> 371 us).
+      const int64_t cap = (int64_t)e->threads * e->k * epc_of(p->dtype);
+      const bool full = p->n * 10 > 9 * cap, sparse = p->n * 10 <= 7 * cap;
+      int nwg = p->ncu * (e->threads >= 512 ? 1
+                          : e->threads == 256 ? (e->k == 1 ? 4 : (e->k == 2 && sparse ? 4 : 2))
+                                              : (e->k >= 3 || (e->k == 2 && full) ? 4 : 8));      // (64 x 3, 838656 x 640: 313 us at four, 331 at eight)
       const int64_t row_bytes = p->n * (p->dtype == FOS_F32 ? 4 : 2);
+      // (below half a GiB the slab sum outweighs it: 200000 x 256 51 us with four per CU, 57 us with eight)
+      if (e->threads == 64 && p->m * row_bytes < (512ll << 20)) nwg = std::min(nwg, 4 * p->ncu);
       const int64_t min_rows = std::max<int64_t>(2 * (int64_t)e->r, (65536 + row_bytes - 1) / row_bytes);   // fp64 slabs
+      if (p->dd_nwg_hint > 0) nwg = p->dd_nwg_hint;
       if (p->m < (int64_t)nwg * min_rows) nwg = (int)std::max<int64_t>(1, p->m / min_rows);
       p->dd_rows_per_wg = (p->m + nwg - 1) / nwg;
       p->dd_nwg = (int)((p->m + p->dd_rows_per_wg - 1) / p->dd_rows_per_wg);
@@ -1088,6 +1098,18 @@ int fos_problem_tune(fos_problem* p, int threads, int chunks, int rows, int work
     return fail(FOS_ERR_UNSUPPORTED, "fos_problem_tune: geometry not instantiated or too narrow for n");
   plan_fused(p, e, workgroups);
   return ensure_workspace(p);
+}
+
+int fos_problem_tune_dd(fos_problem* p, int workgroups) {
+  if (!p || workgroups < 0) return fail(FOS_ERR_ARG, "fos_problem_tune_dd: bad argument");
+  if (p->tall || p->resident) return fail(FOS_ERR_UNSUPPORTED, "fos_problem_tune_dd: the tall / resident plans share the fp32 pass's grid");
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  if (p->slabs_dd) (void)hipFree(p->slabs_dd);
+  if (p->rr_dd) (void)hipFree(p->rr_dd);
+  p->slabs_dd = nullptr; p->rr_dd = nullptr;
+  p->dd_entry = nullptr; p->dd_two_pass_chunks = 0;
+  p->dd_nwg_hint = workgroups;
+  return FOS_OK;                                   // re-planned on the next fp64 pass (ensure_dd)
 }
 
 int fos_problem_set_gbuf(fos_problem* p, float* gbuf) {

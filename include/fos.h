@@ -108,6 +108,9 @@ int fos_problem_plan(const fos_problem* p, int32_t plan[8]);
 int fos_problem_replan(fos_problem* p, unsigned flags);
 /* Benchmark/tuning override of the fused-kernel geometry; returns FOS_ERR_UNSUPPORTED if not instantiated. */
 int fos_problem_tune(fos_problem* p, int threads, int chunks, int rows, int workgroups);
+/* The same for the streaming fp64-accumulating pass (fos_gemv_pair_dd): its workgroup count (0 = back to the planner's);
+ * takes effect with the next fp64 pass.  Synchronises.  Not for the tall / resident plans (they share the fp32 pass's grid). */
+int fos_problem_tune_dd(fos_problem* p, int workgroups);
 /* Use a caller-owned gradient buffer (n + 4 floats, 16-byte aligned) instead of the internal one, e.g. a
  * torch tensor that torch.distributed all-reduces between fos_fista_grad and fos_fista_update. */
 int fos_problem_set_gbuf(fos_problem* p, float* gbuf);
