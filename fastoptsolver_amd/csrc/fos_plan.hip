@@ -325,7 +325,10 @@ void plan_tall(fos_problem* p, const MenuEntry* e) {
   // (a row per 32 lanes, 8 rows per workgroup step: three - 4194304 x 128: 76.1 % at two, 80.0 % at three or four)
   const int per_cu = e->k > 0 ? (p->n * 5 <= 4 * lane_cols ? 4 : (e->k >= 32 ? 3 : 2)) : 4;
   const int64_t rows_min = e->k > 0 ? 384 : 4 * fos::TL_THREADS;
-  int64_t nwg = std::max<int64_t>(1, std::min<int64_t>(per_cu * (int64_t)p->ncu, p->m / rows_min));
+  // Short matrices are latency-bound: up to one workgroup per CU from 64 rows each, whatever rows_min says (20000 x 5: 13.0 ->
+  // 10.9 us per iteration, 10000 x 100: 14.6 -> 11.6 us, 30000 x 100: 16.8 -> 13.1 us; profiles/r03_wg_sweep.txt)
+  const int64_t by_rows = std::max<int64_t>(p->m / rows_min, std::min<int64_t>(p->ncu, p->m / 64));
+  int64_t nwg = std::max<int64_t>(1, std::min<int64_t>(per_cu * (int64_t)p->ncu, by_rows));
   p->rows_per_wg = ((p->m + nwg - 1) / nwg + 3) / 4 * 4;     // a multiple of 4 rows: 16-byte aligned block starts (staged copy)
   p->nwg = (int)((p->m + p->rows_per_wg - 1) / p->rows_per_wg);
   p->nslabs = p->nwg;
