@@ -366,6 +366,16 @@ class Fista:
         _lib.check(rc, "fos_fista_run_fused")
         return True
 
+    def run_chip(self, iters):
+        """`iters` plain iterations in ONE launch with A resident in the LDS of up to all CUs and one grid-wide barrier per
+        iteration (fos_fista_run_chip: tall-skinny fp32 problems, n <= 16).  False when not served."""
+        with self.prob.ctx():
+            rc = self.lib.fos_fista_run_chip(self.h, int(iters))
+        if rc == -4:
+            return False
+        _lib.check(rc, "fos_fista_run_chip")
+        return True
+
     def run_history(self, iters):
         """Device-resident history run: (x_hist [iters, n] float64, hist [iters, 4] float64 =
         {||Ax-b||^2, ||x||_1, ||x||_2^2, ||dx||^2}) as device tensors, or None when this solver configuration /

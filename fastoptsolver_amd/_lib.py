@@ -69,6 +69,7 @@ SIGNATURES = {
     "fos_problem_set_comm_cols": (_i32, [_vp, _vp]),
     "fos_problem_profile": (_i32, [_vp, _i32]),
     "fos_problem_profile_read": (_i32, [_vp, C.POINTER(_f64), C.POINTER(_i64)]),
+    "fos_fista_run_chip": (_i32, [_vp, _i32]),
     "fos_problem_set_fused_stamps": (_i32, [_vp, _vp]),
     "fos_stream_read_probe": (_i32, [_vp, C.c_size_t, _i32, _vp, C.POINTER(_f64), C.POINTER(_f64)]),
     "fos_gemv_pair": (_i32, [_vp, _vp, _f32, _vp, _vp]),

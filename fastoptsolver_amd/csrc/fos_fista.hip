@@ -2,6 +2,7 @@
 // fused, split, recorded, backtracking, resident and lockstep (multi-lambda) runs.  iterative_solvers.py:65-344.
 #include "fos_internal.hpp"
 #include "fused_step.hpp"
+#include "chip_resident.hpp"
 
 using namespace fosapi;
 
@@ -19,6 +20,23 @@ static int launch_fused(const fos::FusedArgs& a, int G, size_t lds, hipStream_t 
   // a plain launch: G = #CUs workgroups of 512 threads and ~136 KiB of LDS are co-resident by grid size (one per CU), which
   // is all hipLaunchCooperativeKernel would check; every grid-wide wait in the kernel is bounded
   hipLaunchKernelGGL(kern, dim3(G), dim3(fos::FZ_THREADS), lds, st, a);
+  LAUNCH_CHECK();
+  return FOS_OK;
+}
+
+template <int NC>
+static int launch_chip(const fos::ChipArgs& a, int G, size_t lds, hipStream_t st) {
+  auto kern = fos::fista_chip_resident_kernel<NC>;
+  static std::atomic<uint64_t> done{0};
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, fos::CR_LDS_BUDGET));
+    done.fetch_or(bit, std::memory_order_release);
+  }
+  // a plain launch of at most #CUs workgroups with up to 150 KiB of LDS each: co-resident by grid size; every wait is bounded
+  hipLaunchKernelGGL(kern, dim3(G), dim3(fos::CR_THREADS), lds, st, a);
   LAUNCH_CHECK();
   return FOS_OK;
 }
@@ -555,6 +573,76 @@ int fos_fista_run_fused(fos_fista* f, int iters) {
   HIP_TRY(hipMemcpyAsync(&bad, p->fz_bar + fos::FZ_LINE, sizeof(unsigned), hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   if (bad) return fail(FOS_ERR_STATE, "fos_fista_run_fused: a grid-wide wait timed out (workgroups not co-resident?); state invalid");
+  return FOS_OK;
+}
+
+// Tall-skinny plain runs with A resident in the LDS of up to all CUs, one grid barrier per iteration (chip_resident.hpp). Opt-in.
+int fos_fista_run_chip(fos_fista* f, int iters) {
+  if (!f || iters < 0) return fail(FOS_ERR_ARG, "fos_fista_run_chip: bad argument");
+  fos_problem* p = f->p;
+  const int nc = p->n <= 8 ? 8 : 16;
+  const int64_t cap = fos::cr_rows_cap(nc);
+  if (p->dtype != FOS_F32 || p->n > 16 || p->comm || p->m < 512 || p->m > cap * (int64_t)p->ncu)
+    return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_chip: fp32 A, n <= 16, 512 <= m <= rows that fit the LDS of all CUs, unsharded");
+  if (!plain_run(f) || f->precise || f->prm.tau_from_state)
+    return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_chip: plain runs only (no adaptive restart, tolerances, device-held step)");
+  if (iters == 0) return FOS_OK;
+  int rc = flush_pending(f);
+  if (rc) return rc;
+  bool stopped = false;
+  if ((rc = refresh_host_scalars(f, &stopped))) return rc;
+  if (stopped) return FOS_OK;
+  // about 1024 rows (four per thread) per workgroup, at most what its LDS holds: the barrier, not the pass, is the cost, and it
+  // grows with the number of workgroups (tools/bench_chip.py: 100000 x 5 took 11.9 us per iteration on 256 workgroups)
+  int64_t G = std::max<int64_t>(1, std::min<int64_t>(p->ncu, (p->m + 1023) / 1024));
+  G = std::max<int64_t>(G, std::min<int64_t>(p->ncu, (p->m + cap - 1) / cap));
+  int64_t rpw = (p->m + G - 1) / G;
+  if (rpw > cap) return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_chip: rows per workgroup exceed the LDS budget");
+  G = (p->m + rpw - 1) / rpw;
+  const size_t np = (size_t)nc + 1;
+  if (!p->cr_part) {
+    HIP_TRY(hipMalloc(&p->cr_part, ((size_t)2 * p->ncu * 17 + 16) * sizeof(double)));
+    HIP_TRY(hipMalloc(&p->cr_bar, fos::FZ_BAR_WORDS * sizeof(unsigned)));
+    HIP_TRY(hipMemsetAsync(p->cr_bar, 0, fos::FZ_BAR_WORDS * sizeof(unsigned), p->stream));
+  }
+  if (iters + 1 > p->fz_beta_cap) {
+    if (p->fz_beta) (void)hipFree(p->fz_beta);
+    p->fz_beta = nullptr; p->fz_beta_cap = 0;
+    HIP_TRY(hipMalloc(&p->fz_beta, (size_t)(iters + 1) * sizeof(double)));
+    p->fz_beta_cap = iters + 1;
+  }
+  std::vector<double> betas((size_t)iters + 1);
+  betas[0] = f->h_beta;
+  for (int k = 0; k < iters; ++k) {
+    host_momentum(f->prm, f->h_k, &f->h_t, &f->h_beta);
+    betas[(size_t)k + 1] = f->h_beta;
+    f->h_k += 1;
+  }
+  HIP_TRY(hipMemcpyAsync(p->fz_beta, betas.data(), betas.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));          // (the host vector must outlive the copy)
+  double* stats = p->cr_part + (size_t)2 * p->ncu * 17;
+  fos::ChipArgs a{};
+  a.A = (const float*)p->A; a.lda = p->lda; a.b = p->b; a.m = p->m; a.n = (int)p->n; a.rows_per_wg = rpw;
+  a.part = p->cr_part; a.x_cur = f->x_cur; a.x_prev = f->x_prev; a.beta = p->fz_beta; a.stats = stats; a.rr_out = stats + 8;
+  a.bar = p->cr_bar; a.iters = iters; a.prox_kind = f->prm.prox_kind;
+  a.tau = f->prm.tau; a.alpha1 = f->prm.alpha1; a.alpha2 = f->prm.alpha2;
+  a.timeout_ticks = 100000000ull * 2ull;
+  (void)np;
+  if ((rc = prof_mark(p, true))) return rc;
+  const size_t lds = fos::cr_lds_bytes(nc, rpw);
+  rc = nc == 8 ? launch_chip<8>(a, (int)G, lds, p->stream) : launch_chip<16>(a, (int)G, lds, p->stream);
+  if (rc) return rc;
+  if ((rc = prof_mark(p, false))) return rc;
+  f->pending = false;
+  f->y_valid = false;                              // the fp32 y vector of the two-launch path is not maintained here
+  hipLaunchKernelGGL(fos::fista_finalize_plain_kernel, dim3(1), dim3(64), 0, p->stream, stats, iters >= 2 ? stats + 4 : (const double*)nullptr,
+                     1, stats + 8, 1, f->scal, f->h_t, f->h_beta, f->h_k);
+  LAUNCH_CHECK();
+  f->plain_count = 0;
+  unsigned bad = 0;
+  HIP_TRY(hipMemcpyAsync(&bad, p->cr_bar + fos::FZ_LINE, sizeof(unsigned), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  if (bad) return fail(FOS_ERR_STATE, "fos_fista_run_chip: a grid-wide wait timed out; state invalid");
   return FOS_OK;
 }
 

@@ -157,6 +157,8 @@ struct fos_problem {
   // multi-lambda pass on the matrix cores (gram_batch.hpp): residual panel and the 16 gradient slab sets
   float* rbuf16 = nullptr;           // panel_rows x 16 floats
   float* rcols16 = nullptr;          // column-sharded candidate pass: m x 16 partial residuals (summed over the ranks)
+  double* cr_part = nullptr;         // chip-resident loop (chip_resident.hpp): [2][G][17] partials + [8] step sums + [1] rr
+  unsigned* cr_bar = nullptr;
   unsigned long long* fz_stamps = nullptr;   // caller-owned (fos_problem_set_fused_stamps), [ncu][8]
   double* mfold = nullptr;           // column-sharded lockstep: 16 x 4 folded step partials (summed over the ranks)
   float* slabs16 = nullptr;          // splits x 16 x n floats

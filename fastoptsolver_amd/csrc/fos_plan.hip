@@ -1062,7 +1062,7 @@ int fos_problem_destroy(fos_problem* p) {
   if (!p) return FOS_OK;
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   void* bufs[] = {p->slabs, p->rr_part, p->rr2_part, p->rvec, p->gbuf_own, p->ybuf, p->dscal, p->part, p->xp, p->q_part, p->bt_out,
-                  p->slabs_dd, p->rr_dd, p->lhist, p->rbuf16, p->rcols16, p->mfold, p->slabs16, p->rneg, p->zeros, p->cp_xchg, p->cp_flags, p->fz_bar, p->fz_part, p->fz_beta,
+                  p->slabs_dd, p->rr_dd, p->lhist, p->rbuf16, p->rcols16, p->mfold, p->cr_part, p->cr_bar, p->slabs16, p->rneg, p->zeros, p->cp_xchg, p->cp_flags, p->fz_bar, p->fz_part, p->fz_beta,
                   p->cp_error};
   for (void* q : bufs)
     if (q) (void)hipFree(q);

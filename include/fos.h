@@ -279,6 +279,12 @@ int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters);
  * otherwise).  Synchronises at the end (reports a timed-out grid-wide wait as FOS_ERR_STATE).  The default two-launch step
  * measures faster: this entry point exists so that the comparison is a measurement. */
 int fos_fista_run_fused(fos_fista* f, int iters);
+/* Tall-skinny problems beyond one CU's LDS, OPT-IN (csrc/chip_resident.hpp): `iters` plain iterations (no adaptive restart,
+ * tolerances or backtracking: FOS_ERR_UNSUPPORTED otherwise) in ONE launch with A resident in the LDS of up to all CUs and one
+ * grid-wide barrier per iteration - every workgroup reads all partial gradients (n <= 16) and applies the identical fp64 update
+ * to its copy of the iterate.  fp32 A, n <= 16, 512 <= m <= (150 KiB / row bytes) x #CUs, unsharded.  Same state hand-over as
+ * fos_fista_run (the two can be mixed).  Synchronises at the end (it reports a timed-out barrier). */
+int fos_fista_run_chip(fos_fista* f, int iters);
 /* Measurement hook of the persistent step: stamps = device buffer of #CUs x 8 uint64 (NULL = off); every workgroup then
  * records the 100 MHz wall clock of the LAST iteration of a fos_fista_run_fused call - [0] phase A starts, [1] phase A
  * ends, [2] behind the first grid barrier, [3] phase B ends, [4] behind the second grid barrier.  The buffer is borrowed. */

@@ -1663,3 +1663,50 @@ def test_distinct_handles_from_distinct_threads(fos):
         for i in range(len(shapes)):
             for a, c in zip(seq[i], par[i]):
                 assert torch.equal(a, c), (i, shapes[i])
+
+
+@pytest.mark.parametrize("m,n", [(9000, 5), (20000, 5), (100000, 5), (300001, 8), (50000, 13), (40000, 16), (700, 3), (300, 3)])
+def test_chip_resident_plain_loop(fos, m, n):
+    """Opt-in (fos_fista_run_chip): tall-skinny plain runs with A resident in the LDS of up to all CUs and ONE grid barrier
+    per iteration - every workgroup reads all partial gradients and updates its own copy of the iterate.  Against the oracle
+    (1e-5) and the default two-launch loop (1e-6) for FISTA (lasso; l2 in the smooth
+    part), FISTA-delta and fused ISTA with the elastic-net prox; the state carries over between chip calls and between the
+    two forms, step norms included; ill-conditioned columns (the reference's unstandardised features); unsupported runs refuse."""
+    from fastoptsolver_amd import _core
+    rng = np.random.default_rng(m + n)
+    A = rng.standard_normal((m, n)).astype(np.float32)
+    A[:, 0] *= 300.0                                          # unstandardised scale, as in easy_boston_data.py
+    b = (A.astype(np.float64) @ rng.standard_normal(n) + rng.standard_normal(m)).astype(np.float32)
+    A64, b64 = A.astype(np.float64), b.astype(np.float64)
+    prob = fos.prepare(torch.as_tensor(A).cuda(), b)
+    prob.replan(no_resident=True)
+    L = float(np.linalg.norm(A64, 2) ** 2)
+    lam = float(np.max(np.abs(A64.T @ b64)))
+    cases = [dict(mode=_core._lib.MODE_FISTA, a1=0.05 * lam, a2=0.0, kind=_core._lib.PROX_L1),
+             dict(mode=_core._lib.MODE_FISTA, a1=0.02 * lam, a2=0.7, kind=_core._lib.PROX_L1),
+             dict(mode=_core._lib.MODE_DELTA, a1=0.05 * lam, a2=0.0, kind=_core._lib.PROX_L1, delta=3.0),
+             dict(mode=_core._lib.MODE_ISTA, a1=0.05 * lam, a2=0.5, kind=_core._lib.PROX_ENET)]
+    for c in cases:
+        tau = 1.0 / (L + (c["a2"] if c["kind"] == _core._lib.PROX_L1 and c["a2"] > 0 else 0.0))
+        kw = dict(mode=c["mode"], delta=c.get("delta", 0.0), prox_kind=c["kind"])
+        ref = _core.Fista(prob); ref.reset(tau, c["a1"], c["a2"], **kw); ref.run(40)
+        ch = _core.Fista(prob); ch.reset(tau, c["a1"], c["a2"], **kw)
+        served = ch.run_chip(7)
+        if m < 512:
+            assert not served
+            return
+        assert served and ch.run_chip(1) and ch.run_chip(12)           # state carries over between chip calls ...
+        ch.run(10)                                                     # ... into the two-launch form ...
+        assert ch.run_chip(10)                                         # ... and back
+        xr, xc = ref.x_tensor().cpu().numpy(), ch.x_tensor().cpu().numpy()
+        assert _data.rel(xc, xr) < 1e-6, c                              # (the two-launch plain loop hands y over as fp32)
+        sr, sc = ref.status(), ch.status()
+        # (near a fixed point the two-launch loop's step norms are the rounding noise of its fp32 y: absolute slack)
+        slack = 1e-6 * float(np.linalg.norm(xr))
+        assert int(sc.k) == int(sr.k) == 40 and sc.this_step == pytest.approx(sr.this_step, rel=1e-3, abs=slack)
+        assert sc.prev_step == pytest.approx(sr.prev_step, rel=1e-3, abs=slack) and sc.rr == pytest.approx(sr.rr, rel=1e-5)
+        if c["mode"] == _core._lib.MODE_FISTA:
+            x_o = orc.fista(A64, b64, "elasticnet" if c["a2"] else "lasso", c["a1"], c["a2"], max_iter=40, L=L)
+            assert _data.rel(xc, x_o) < TOL, c
+    st = _core.Fista(prob); st.reset(1.0 / L, 0.05 * lam, 0.0, adaptive_restart=True)
+    assert not st.run_chip(3)                                          # data-dependent control: not served
