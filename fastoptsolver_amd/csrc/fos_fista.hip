@@ -430,6 +430,10 @@ int fos_fista_run(fos_fista* f, int iters) {
   // Plain run: no data-dependent control (adaptive restart / stopping tolerances).  t_k and beta_k are then a fixed
   // sequence: the host passes beta_k to both kernels by value, and the scalar bookkeeping kernel runs once per call
   // instead of once per iteration (two launches per iteration instead of three).
+  if (plain_run(f) && p->chip_on && !f->precise && !f->prm.tau_from_state) {       // opt-in: tall-skinny, A in the LDS of all CUs
+    const int rcc = fos_fista_run_chip(f, iters);
+    if (rcc != FOS_ERR_UNSUPPORTED) return rcc;
+  }
   if (plain_run(f) && p->fused_on && !f->precise && !f->prm.tau_from_state) {      // opt-in: the one-launch persistent step
     const int rcf = fos_fista_run_fused(f, iters);
     if (rcf != FOS_ERR_UNSUPPORTED) return rcf;

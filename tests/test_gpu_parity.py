@@ -1710,3 +1710,11 @@ def test_chip_resident_plain_loop(fos, m, n):
             assert _data.rel(xc, x_o) < TOL, c
     st = _core.Fista(prob); st.reset(1.0 / L, 0.05 * lam, 0.0, adaptive_restart=True)
     assert not st.run_chip(3)                                          # data-dependent control: not served
+    # the plan flag routes the Python boundary's plain calls through it (FOS_PLAN_CHIP_RESIDENT); flagged runs fall through
+    prob2 = fos.prepare(torch.as_tensor(A).cuda(), b)
+    prob2.replan(chip_resident=True)
+    assert prob2.plan()["chip_resident"] == 1
+    x1 = fos.fista(prob2, None, "lasso", 0.05 * lam, 0.0, max_iter=60, L=L)
+    assert _data.rel(_np(x1), orc.fista(A64, b64, "lasso", 0.05 * lam, 0.0, max_iter=60, L=L)) < TOL
+    x2 = fos.fista(prob2, None, "lasso", 0.05 * lam, 0.0, max_iter=60, L=L, adaptive_restart=True)
+    assert _data.rel(_np(x2), orc.fista(A64, b64, "lasso", 0.05 * lam, 0.0, max_iter=60, L=L, adaptive_restart=True)) < TOL
