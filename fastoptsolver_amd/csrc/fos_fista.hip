@@ -432,7 +432,8 @@ int fos_fista_run(fos_fista* f, int iters) {
   // instead of once per iteration (two launches per iteration instead of three).
   if (plain_run(f) && p->chip_on && !f->precise && !f->prm.tau_from_state) {       // opt-in: tall-skinny, A in the LDS of all CUs
     const int rcc = fos_fista_run_chip(f, iters);
-    if (rcc != FOS_ERR_UNSUPPORTED) return rcc;
+    // not served, or its grid could not become co-resident within the bound (state untouched): the two-launch loop below
+    if (rcc != FOS_ERR_UNSUPPORTED && rcc != FOS_ERR_STATE) return rcc;
   }
   if (plain_run(f) && p->fused_on && !f->precise && !f->prm.tau_from_state) {      // opt-in: the one-launch persistent step
     const int rcf = fos_fista_run_fused(f, iters);
@@ -617,6 +618,8 @@ int fos_fista_run_chip(fos_fista* f, int iters) {
   }
   std::vector<double> betas((size_t)iters + 1);
   betas[0] = f->h_beta;
+  const long long k_before = f->h_k;
+  const double t_before = f->h_t, beta_before = f->h_beta;
   for (int k = 0; k < iters; ++k) {
     host_momentum(f->prm, f->h_k, &f->h_t, &f->h_beta);
     betas[(size_t)k + 1] = f->h_beta;
@@ -637,16 +640,24 @@ int fos_fista_run_chip(fos_fista* f, int iters) {
   rc = nc == 8 ? launch_chip<8>(a, (int)G, lds, p->stream) : launch_chip<16>(a, (int)G, lds, p->stream);
   if (rc) return rc;
   if ((rc = prof_mark(p, false))) return rc;
+  // A grid-wide wait that ran out (workgroups not co-resident: another kernel held CUs for longer than the bound) ends the
+  // launch BEFORE anything is written back: the iterate on the device is the one the call started from.  The handle's
+  // momentum counters are put back, the barrier words cleared, and the caller is told - it can run the two-launch loop.
+  unsigned bad = 0;
+  HIP_TRY(hipMemcpyAsync(&bad, p->cr_bar + fos::FZ_LINE, sizeof(unsigned), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  if (bad) {
+    f->h_k = k_before; f->h_t = t_before; f->h_beta = beta_before;
+    HIP_TRY(hipMemsetAsync(p->cr_bar, 0, fos::FZ_BAR_WORDS * sizeof(unsigned), p->stream));
+    return fail(FOS_ERR_STATE, "fos_fista_run_chip: a grid-wide wait timed out (workgroups not co-resident); the state is "
+                               "the one before the call");
+  }
   f->pending = false;
   f->y_valid = false;                              // the fp32 y vector of the two-launch path is not maintained here
   hipLaunchKernelGGL(fos::fista_finalize_plain_kernel, dim3(1), dim3(64), 0, p->stream, stats, iters >= 2 ? stats + 4 : (const double*)nullptr,
                      1, stats + 8, 1, f->scal, f->h_t, f->h_beta, f->h_k);
   LAUNCH_CHECK();
   f->plain_count = 0;
-  unsigned bad = 0;
-  HIP_TRY(hipMemcpyAsync(&bad, p->cr_bar + fos::FZ_LINE, sizeof(unsigned), hipMemcpyDeviceToHost, p->stream));
-  HIP_TRY(hipStreamSynchronize(p->stream));
-  if (bad) return fail(FOS_ERR_STATE, "fos_fista_run_chip: a grid-wide wait timed out; state invalid");
   return FOS_OK;
 }
 
