@@ -29,7 +29,7 @@ struct ChipArgs {
   const float* A; int64_t lda; const float* b; int64_t m; int n; int64_t rows_per_wg;
   double* part;            // [2][G][NC + 1]: partial gradient and ||r||^2 of workgroup w, by parity of the iteration
   double* x_cur; double* x_prev;      // n doubles each (state)
-  const double* beta;      // [iters + 1]
+  const double* beta;      // [iters + 1]: beta[k] forms y_k from (x_k, x_{k-1}) (the momentum sequence of a plain run is data-free)
   double* stats;           // [2][4]: {sum d^2, sum gf^2, sum |x|, sum x^2} of the last ([0]) and the previous ([1]) iteration
   double* rr_out;          // ||A y - b||^2 of the last iteration's pass
   unsigned* bar;           // FZ_BAR_WORDS words, zero between launches
@@ -80,8 +80,7 @@ __global__ __launch_bounds__(CR_THREADS) void fista_chip_resident_kernel(ChipArg
   double st_cur[4] = {0.0, 0.0, 0.0, 0.0}, st_prev[4] = {0.0, 0.0, 0.0, 0.0};
 
   for (int it = 0; it < a.iters; ++it) {
-    const double beta = a.beta[it], beta_next = a.beta[it + 1];
-    (void)beta_next;
+    const double beta = a.beta[it];
     double y[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) y[c] = form_y(xc[c], xp[c], beta);

@@ -604,7 +604,6 @@ int fos_fista_run_chip(fos_fista* f, int iters) {
   int64_t rpw = (p->m + G - 1) / G;
   if (rpw > cap) return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_chip: rows per workgroup exceed the LDS budget");
   G = (p->m + rpw - 1) / rpw;
-  const size_t np = (size_t)nc + 1;
   if (!p->cr_part) {
     HIP_TRY(hipMalloc(&p->cr_part, ((size_t)2 * p->ncu * 17 + 16) * sizeof(double)));
     HIP_TRY(hipMalloc(&p->cr_bar, fos::FZ_BAR_WORDS * sizeof(unsigned)));
@@ -634,7 +633,6 @@ int fos_fista_run_chip(fos_fista* f, int iters) {
   a.bar = p->cr_bar; a.iters = iters; a.prox_kind = f->prm.prox_kind;
   a.tau = f->prm.tau; a.alpha1 = f->prm.alpha1; a.alpha2 = f->prm.alpha2;
   a.timeout_ticks = 100000000ull * 2ull;
-  (void)np;
   if ((rc = prof_mark(p, true))) return rc;
   const size_t lds = fos::cr_lds_bytes(nc, rpw);
   rc = nc == 8 ? launch_chip<8>(a, (int)G, lds, p->stream) : launch_chip<16>(a, (int)G, lds, p->stream);
