@@ -204,22 +204,24 @@ class Problem:
         plan["cluster"] = (flags >> 4) & 1        # multi-lambda pass: one-read cluster form planned (after its first run)
         plan["interleave"] = (flags >> 5) & 1     # streaming pass: rows dealt round-robin to the workgroups
         plan["fused_mfma"] = (flags >> 6) & 1     # opt-in: plain runs take the one-launch persistent step
-        plan["chip_resident"] = (flags >> 7) & 1  # opt-in: tall-skinny plain runs keep A in the LDS of up to all CUs
+        plan["chip_resident"] = (flags >> 7) & 1  # tall-skinny plain runs keep A in the LDS of up to all CUs: forced on
         return plan
 
     def replan(self, no_resident=False, no_tall=False, no_wide=False, no_colblock=False, cluster=None, interleave=None,
-               fused_mfma=False, chip_resident=False):
+               fused_mfma=False, chip_resident=None):
         """Re-run the planner with kernel families switched off; ``cluster`` / ``interleave``: True / False force the
         one-read cluster form of the multi-weight pass / the round-robin row order on or off, None leaves the planner's
         choice; ``fused_mfma=True`` opts plain runs in to the one-launch persistent step (fos_fista_run_fused),
-        ``chip_resident=True`` tall-skinny plain runs (n <= 16) to the chip-resident loop (fos_fista_run_chip)
+        ``chip_resident=True`` / ``False`` takes the chip-resident loop for tall-skinny plain runs (fos_fista_run_chip)
+        wherever it is served / never, None leaves the planner's region (n <= 8, up to 131072 rows)
         (fos_problem_replan): tests and A/B measurements.
         Call before creating Fista handles on this problem."""
         flags = ((_lib.PLAN_NO_RESIDENT if no_resident else 0) | (_lib.PLAN_NO_TALL if no_tall else 0) |
                  (_lib.PLAN_NO_WIDE if no_wide else 0) | (_lib.PLAN_NO_COLBLOCK if no_colblock else 0) |
                  (0 if cluster is None else (_lib.PLAN_CLUSTER if cluster else _lib.PLAN_NO_CLUSTER)) |
                  (0 if interleave is None else (_lib.PLAN_INTERLEAVE if interleave else _lib.PLAN_NO_INTERLEAVE)) |
-                 (_lib.PLAN_FUSED_MFMA if fused_mfma else 0) | (_lib.PLAN_CHIP_RESIDENT if chip_resident else 0))
+                 (_lib.PLAN_FUSED_MFMA if fused_mfma else 0) |
+                 (0 if chip_resident is None else (_lib.PLAN_CHIP_RESIDENT if chip_resident else _lib.PLAN_NO_CHIP_RESIDENT)))
         with self.ctx():
             _lib.check(self.lib.fos_problem_replan(self.h, flags), "fos_problem_replan")
 

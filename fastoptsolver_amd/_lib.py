@@ -10,7 +10,7 @@ FOS_F32, FOS_BF16 = 0, 1
 MODE_FISTA, MODE_DELTA, MODE_ISTA = 0, 1, 2
 PROX_L1, PROX_ENET = 0, 1
 STOP_NONE, STOP_STEP, STOP_RATIO, STOP_GRAD, STOP_LS_STALL = 0, 1, 2, 3, 4
-PLAN_NO_RESIDENT, PLAN_NO_TALL, PLAN_NO_WIDE, PLAN_NO_COLBLOCK, PLAN_CLUSTER, PLAN_INTERLEAVE, PLAN_NO_INTERLEAVE, PLAN_NO_CLUSTER, PLAN_FUSED_MFMA, PLAN_CHIP_RESIDENT = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+PLAN_NO_RESIDENT, PLAN_NO_TALL, PLAN_NO_WIDE, PLAN_NO_COLBLOCK, PLAN_CLUSTER, PLAN_INTERLEAVE, PLAN_NO_INTERLEAVE, PLAN_NO_CLUSTER, PLAN_FUSED_MFMA, PLAN_CHIP_RESIDENT, PLAN_NO_CHIP_RESIDENT = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024
 
 
 class FistaParams(C.Structure):

@@ -430,7 +430,12 @@ int fos_fista_run(fos_fista* f, int iters) {
   // Plain run: no data-dependent control (adaptive restart / stopping tolerances).  t_k and beta_k are then a fixed
   // sequence: the host passes beta_k to both kernels by value, and the scalar bookkeeping kernel runs once per call
   // instead of once per iteration (two launches per iteration instead of three).
-  if (plain_run(f) && p->chip_on && !f->precise && !f->prm.tau_from_state) {       // opt-in: tall-skinny, A in the LDS of all CUs
+  // Tall-skinny plain runs: A in the LDS of up to all CUs, one grid barrier per iteration (chip_resident.hpp).  The planner's
+  // own region is where it measured at least 1.4x ahead of the two launches below (tools/bench_chip.py: 9000 ... 100000 x 5
+  // 5.6-7.6 us per iteration against 10.8-11.1); FOS_PLAN_CHIP_RESIDENT / FOS_PLAN_NO_CHIP_RESIDENT widen it to every served
+  // shape / switch it off.
+  const bool chip_region = p->dtype == FOS_F32 && p->n <= 8 && p->m >= 512 && p->m <= 131072 && iters >= 8 && !p->comm;
+  if (plain_run(f) && (p->chip_mode == 1 || (p->chip_mode == 0 && chip_region)) && !f->precise && !f->prm.tau_from_state) {
     const int rcc = fos_fista_run_chip(f, iters);
     // not served, or its grid could not become co-resident within the bound (state untouched): the two-launch loop below
     if (rcc != FOS_ERR_UNSUPPORTED && rcc != FOS_ERR_STATE) return rcc;

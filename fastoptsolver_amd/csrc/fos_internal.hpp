@@ -174,7 +174,7 @@ struct fos_problem {
   unsigned cp_epoch = 1;
   int cp_mode = 0;                   // 0: planner's choice, 1: FOS_PLAN_CLUSTER, 2: FOS_PLAN_NO_CLUSTER
   // fused persistent step (fused_step.hpp, fos_fista_run_fused): barrier words, per-workgroup partials, beta sequence
-  bool chip_on = false;              // FOS_PLAN_CHIP_RESIDENT: plain fos_fista_run calls take fos_fista_run_chip where served
+  int chip_mode = 0;                 // 0: planner (fos_fista_run_chip where it measured ahead), 1: FOS_PLAN_CHIP_RESIDENT, 2: never
   bool fused_on = false;             // FOS_PLAN_FUSED_MFMA: plain fos_fista_run calls take fos_fista_run_fused where served
   unsigned* fz_bar = nullptr;
   double* fz_part = nullptr;

@@ -975,7 +975,7 @@ int fos_problem_replan(fos_problem* p, unsigned flags) {
   if (p->col_sharded) return fail(FOS_ERR_UNSUPPORTED, "fos_problem_replan: a column-sharded problem keeps its two-phase plan");
   if (flags & ~(unsigned)(FOS_PLAN_NO_RESIDENT | FOS_PLAN_NO_TALL | FOS_PLAN_NO_WIDE | FOS_PLAN_NO_COLBLOCK | FOS_PLAN_CLUSTER |
                            FOS_PLAN_INTERLEAVE | FOS_PLAN_NO_INTERLEAVE | FOS_PLAN_NO_CLUSTER | FOS_PLAN_FUSED_MFMA |
-                           FOS_PLAN_CHIP_RESIDENT))
+                           FOS_PLAN_CHIP_RESIDENT | FOS_PLAN_NO_CHIP_RESIDENT))
     return fail(FOS_ERR_ARG, "fos_problem_replan: unknown flag");
   // the multi-lambda workspace follows its own plan (one-read cluster form or two products): rebuilt on first use
   {
@@ -986,8 +986,9 @@ int fos_problem_replan(fos_problem* p, unsigned flags) {
     p->cp_cs = p->cp_clusters = 0;
     p->cp_mode = (flags & FOS_PLAN_CLUSTER) ? 1 : (flags & FOS_PLAN_NO_CLUSTER) ? 2 : 0;
     p->fused_on = (flags & FOS_PLAN_FUSED_MFMA) != 0;
-    p->chip_on = (flags & FOS_PLAN_CHIP_RESIDENT) != 0;
-    flags &= ~(unsigned)(FOS_PLAN_CLUSTER | FOS_PLAN_NO_CLUSTER | FOS_PLAN_FUSED_MFMA | FOS_PLAN_CHIP_RESIDENT);
+    p->chip_mode = (flags & FOS_PLAN_CHIP_RESIDENT) ? 1 : (flags & FOS_PLAN_NO_CHIP_RESIDENT) ? 2 : 0;
+    flags &= ~(unsigned)(FOS_PLAN_CLUSTER | FOS_PLAN_NO_CLUSTER | FOS_PLAN_FUSED_MFMA | FOS_PLAN_CHIP_RESIDENT |
+                         FOS_PLAN_NO_CHIP_RESIDENT);
   }
   // workspace sized for the old plan (slab stride, fp64 slabs) is dropped and rebuilt
   void* drop[] = {p->slabs, p->rr_part, p->rr2_part, p->slabs_dd, p->rr_dd};
@@ -1083,7 +1084,7 @@ int fos_problem_plan(const fos_problem* p, int32_t plan[8]) {
   plan[5] = p->nslabs;
   plan[6] = (p->path == 0 ? 1 : 0) | (p->resident ? 2 : 0) | (p->tall ? 4 : 0) | (p->colblock ? 8 : 0) | (p->cp_cs ? 16 : 0) |
             ((p->il && p->entry && p->entry->with_g_il && p->path == 0 && !p->colblock && !p->tall) ? 32 : 0) |
-            (p->fused_on ? 64 : 0) | (p->chip_on ? 128 : 0);
+            (p->fused_on ? 64 : 0) | (p->chip_mode == 1 ? 128 : 0);
   plan[7] = p->ncu;
   return FOS_OK;
 }

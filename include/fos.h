@@ -43,10 +43,12 @@ enum { FOS_PLAN_NO_RESIDENT = 1, FOS_PLAN_NO_TALL = 2, FOS_PLAN_NO_WIDE = 4, FOS
        FOS_PLAN_FUSED_MFMA = 256,   /* OPT IN: plain fos_fista_run calls take the one-launch persistent step of
                                        fos_fista_run_fused (LDS-staged panels, row dots on the matrix cores, resident
                                        iterate) wherever the shape is served */
-       FOS_PLAN_CHIP_RESIDENT = 512 /* OPT IN: plain fos_fista_run calls on tall-skinny problems (n <= 16) take
-                                       fos_fista_run_chip (A resident in the LDS of up to all CUs, one grid barrier per
-                                       iteration) wherever served; problems that fit ONE CU's LDS keep the single-workgroup
-                                       resident loop */ };
+       FOS_PLAN_CHIP_RESIDENT = 512, /* plain fos_fista_run calls on tall-skinny problems (n <= 16) take fos_fista_run_chip
+                                       (A resident in the LDS of up to all CUs, one grid barrier per iteration) WHEREVER
+                                       it is served ...                                                              */
+       FOS_PLAN_NO_CHIP_RESIDENT = 1024 /* ... or never; neither bit: the planner takes it where it measured at least 1.4x
+                                       ahead - fp32, n <= 8, 512 <= m <= 131072 rows, calls of 8 iterations or more.
+                                       Problems that fit ONE CU's LDS keep the single-workgroup resident loop. */ };
 
 typedef struct fos_problem fos_problem;   /* A, b, launch plan, workspace            */
 typedef struct fos_comm fos_comm;         /* communicator of a row-sharded problem   */
@@ -102,7 +104,7 @@ int fos_problem_set_stream(fos_problem* p, void* stream);
  *               single pass is the row-per-thread kernel, which has no alignment requirements; bit 3: rows wider than
  *               any single-pass kernel - column blocks through the streaming kernel in two phases, A read twice;
  *               bit 4: set once fos_fista_run_multi has planned the one-read cluster form of the matrix-core pass;
- *               bit 5: the streaming pass deals its rows round-robin to the workgroups; bit 6: FOS_PLAN_FUSED_MFMA; bit 7: FOS_PLAN_CHIP_RESIDENT), CUs} */
+ *               bit 5: the streaming pass deals its rows round-robin to the workgroups; bit 6: FOS_PLAN_FUSED_MFMA; bit 7: the chip-resident loop is forced on), CUs} */
 int fos_problem_plan(const fos_problem* p, int32_t plan[8]);
 /* Re-run the planner with kernel families switched off (FOS_PLAN_* bits): NO_RESIDENT keeps small problems off the
  * one-launch LDS-resident loop, NO_TALL keeps n <= 64 off the row-per-thread pass, NO_WIDE keeps 16384 < n <= 32768 off

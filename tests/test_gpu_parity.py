@@ -1679,7 +1679,7 @@ def test_chip_resident_plain_loop(fos, m, n):
     b = (A.astype(np.float64) @ rng.standard_normal(n) + rng.standard_normal(m)).astype(np.float32)
     A64, b64 = A.astype(np.float64), b.astype(np.float64)
     prob = fos.prepare(torch.as_tensor(A).cuda(), b)
-    prob.replan(no_resident=True)
+    prob.replan(no_resident=True, chip_resident=False)       # run() = the two-launch loop; run_chip() is explicit below
     L = float(np.linalg.norm(A64, 2) ** 2)
     lam = float(np.max(np.abs(A64.T @ b64)))
     cases = [dict(mode=_core._lib.MODE_FISTA, a1=0.05 * lam, a2=0.0, kind=_core._lib.PROX_L1),
@@ -1710,11 +1710,21 @@ def test_chip_resident_plain_loop(fos, m, n):
             assert _data.rel(xc, x_o) < TOL, c
     st = _core.Fista(prob); st.reset(1.0 / L, 0.05 * lam, 0.0, adaptive_restart=True)
     assert not st.run_chip(3)                                          # data-dependent control: not served
-    # the plan flag routes the Python boundary's plain calls through it (FOS_PLAN_CHIP_RESIDENT); flagged runs fall through
+    # The Python boundary's plain calls take it by the planner's choice (n <= 8, up to 131072 rows) or by the plan flag
+    # (FOS_PLAN_CHIP_RESIDENT: wherever served); flagged runs fall through to the two-launch loop.  Kernel timing tells
+    # which loop ran: the chip loop is ONE profiled launch per call, the two-launch loop one per iteration.
+    x_o = orc.fista(A64, b64, "lasso", 0.05 * lam, 0.0, max_iter=60, L=L)
+    for force, expect_chip in ((None, n <= 8 and 512 <= m <= 131072), (True, m >= 512), (False, False)):
+        prob2 = fos.prepare(torch.as_tensor(A).cuda(), b)
+        prob2.replan(no_resident=True, chip_resident=force)
+        assert prob2.plan()["chip_resident"] == (1 if force else 0)
+        prob2.profile(1); prob2.profile_read()
+        x1 = fos.fista(prob2, None, "lasso", 0.05 * lam, 0.0, max_iter=60, L=L)
+        launches = prob2.profile_read()[1]
+        prob2.profile(0)
+        assert _data.rel(_np(x1), x_o) < TOL, force
+        assert (launches <= 2) == expect_chip, (force, launches)
     prob2 = fos.prepare(torch.as_tensor(A).cuda(), b)
-    prob2.replan(chip_resident=True)
-    assert prob2.plan()["chip_resident"] == 1
-    x1 = fos.fista(prob2, None, "lasso", 0.05 * lam, 0.0, max_iter=60, L=L)
-    assert _data.rel(_np(x1), orc.fista(A64, b64, "lasso", 0.05 * lam, 0.0, max_iter=60, L=L)) < TOL
+    prob2.replan(no_resident=True, chip_resident=True)
     x2 = fos.fista(prob2, None, "lasso", 0.05 * lam, 0.0, max_iter=60, L=L, adaptive_restart=True)
     assert _data.rel(_np(x2), orc.fista(A64, b64, "lasso", 0.05 * lam, 0.0, max_iter=60, L=L, adaptive_restart=True)) < TOL

@@ -11,7 +11,7 @@ torch.cuda.set_device(0)
 for m, n in [(9000, 5), (20000, 5), (50000, 5), (100000, 5), (300000, 5), (1000000, 5), (20000, 16), (100000, 16), (500000, 16), (100000, 8)]:
     A = torch.randn(m, n, device="cuda"); b = torch.randn(m, device="cuda")
     prob = fos.prepare(A, b)
-    prob.replan(no_resident=True)
+    prob.replan(no_resident=True, chip_resident=False)       # run() = the two-launch loop
     L = float((A.double() ** 2).sum())
     res = {}
     for name in ("two-launch", "chip"):
