@@ -36,6 +36,11 @@ struct ChipArgs {
   int iters; int prox_kind;
   double tau, alpha1, alpha2;
   unsigned long long timeout_ticks;
+  // CTRL = true (adaptive restart / step or ratio tolerances: iterative_solvers.py:209-221, :235-242): momentum and stops are
+  // decided on the device every iteration - by EVERY workgroup alike, from its own copy of the iterate's step norms: no
+  // exchange beyond the one barrier; `beta` is unused, the scalar state is read from and written back to `scal`
+  FistaScalars* scal;
+  FistaParams prm;
 };
 
 __host__ __device__ inline size_t cr_lds_bytes(int nc, int64_t rows) {
@@ -43,7 +48,7 @@ __host__ __device__ inline size_t cr_lds_bytes(int nc, int64_t rows) {
 }
 __host__ __device__ inline int64_t cr_rows_cap(int nc) { return (CR_LDS_BUDGET - 1024) / ((nc + 4) * 4 + 4); }
 
-template <int NC>
+template <int NC, bool CTRL>
 __global__ __launch_bounds__(CR_THREADS) void fista_chip_resident_kernel(ChipArgs a) {
   constexpr int S = NC + 4;                                    // row stride in floats (16-byte aligned, not a power of two)
   constexpr int NP = NC + 1;
@@ -78,9 +83,18 @@ __global__ __launch_bounds__(CR_THREADS) void fista_chip_resident_kernel(ChipArg
 #pragma unroll
   for (int c = 0; c < NC; ++c) { xc[c] = c < n ? a.x_cur[c] : 0.0; xp[c] = c < n ? a.x_prev[c] : 0.0; }
   double st_cur[4] = {0.0, 0.0, 0.0, 0.0}, st_prev[4] = {0.0, 0.0, 0.0, 0.0};
+  // the scalar state machine of a controlled run, replicated like the iterate (fista_finalize_body, reduce_update.hpp)
+  double c_t = 1.0, c_beta = 0.0, c_this = 0.0, c_prev = 0.0, c_ratio = INFINITY;
+  long long c_k = 0;
+  int c_restarts = 0, c_stop = STOP_NONE;
+  if constexpr (CTRL) {
+    c_t = a.scal->t_prev; c_beta = a.scal->beta; c_this = a.scal->this_step; c_prev = a.scal->prev_step; c_ratio = a.scal->ratio;
+    c_k = a.scal->k; c_restarts = a.scal->restarts; c_stop = a.scal->stopped;
+  }
+  int done = 0;
 
-  for (int it = 0; it < a.iters; ++it) {
-    const double beta = a.beta[it];
+  for (int it = 0; it < a.iters && c_stop == STOP_NONE; ++it) {
+    const double beta = CTRL ? c_beta : a.beta[it];
     double y[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) y[c] = form_y(xc[c], xp[c], beta);
@@ -147,9 +161,38 @@ __global__ __launch_bounds__(CR_THREADS) void fista_chip_resident_kernel(ChipArg
         xc[c] = xn;
       }
     }
+    if constexpr (CTRL) {                                        // identical inputs in every thread of every workgroup
+      const double step = sqrt(st_cur[0]);
+      const double prev = c_this;
+      const double ratio = prev > 0.0 ? step / prev : INFINITY;
+      if (a.prm.mode == MODE_FISTA) {
+        if (a.prm.adaptive_restart && ratio > a.prm.restart_threshold) {
+          c_t = 1.0; c_beta = 0.0; c_restarts += 1;
+        } else {
+          const double t_new = 0.5 * (1.0 + sqrt(1.0 + 4.0 * c_t * c_t));
+          c_beta = (c_t - 1.0) / t_new;
+          c_t = t_new;
+        }
+      } else if (a.prm.mode == MODE_DELTA) {
+        const double kk = (double)(c_k + 1);
+        c_beta = kk / (kk + 1.0 + a.prm.delta);
+      } else {
+        c_beta = 0.0;
+      }
+      c_prev = prev; c_this = step; c_ratio = ratio; c_k += 1;
+      if (a.prm.tol_step > 0.0 && step < a.prm.tol_step) c_stop = STOP_STEP;
+      if (c_stop == STOP_NONE && a.prm.tol_ratio > 0.0 && ratio < a.prm.tol_ratio) c_stop = STOP_RATIO;
+    }
+    done += 1;
     __syncthreads();                                             // gt is rewritten by the next iteration's gather
   }
-  if (w == 0 && tid == 0) {
+  if (w == 0 && tid == 0 && done > 0) {
+    if constexpr (CTRL) {
+      FistaScalars* sc = a.scal;
+      sc->t_prev = c_t; sc->beta = c_beta; sc->this_step = c_this; sc->prev_step = c_prev; sc->ratio = c_ratio;
+      sc->rr = gt[NC]; sc->gnorm2 = st_cur[1]; sc->xnorm1 = st_cur[2]; sc->xnorm2 = st_cur[3];
+      sc->k = c_k; sc->restarts = c_restarts; sc->stopped = c_stop;
+    }
 #pragma unroll
     for (int c = 0; c < NC; ++c)
       if (c < n) { a.x_cur[c] = xc[c]; a.x_prev[c] = xp[c]; }

@@ -24,9 +24,9 @@ static int launch_fused(const fos::FusedArgs& a, int G, size_t lds, hipStream_t 
   return FOS_OK;
 }
 
-template <int NC>
+template <int NC, bool CTRL>
 static int launch_chip(const fos::ChipArgs& a, int G, size_t lds, hipStream_t st) {
-  auto kern = fos::fista_chip_resident_kernel<NC>;
+  auto kern = fos::fista_chip_resident_kernel<NC, CTRL>;
   static std::atomic<uint64_t> done{0};
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
@@ -405,6 +405,20 @@ int fos_fista_run(fos_fista* f, int iters) {
   fos_problem* p = f->p;
   if (iters == 0) return FOS_OK;
   if (p->resident) return run_resident(f, iters, nullptr, nullptr);
+  // Tall-skinny runs without backtracking / history: A in the LDS of up to all CUs, one grid barrier per iteration
+  // (chip_resident.hpp); adaptive restart and the step / ratio stops are decided on the device by every workgroup alike.  The
+  // planner's own region is where the plain loop measured at least 1.4x ahead of the two launches below (tools/bench_chip.py:
+  // 9000 ... 100000 x 5 5.6-7.7 us per iteration against 10.8-11.2; runs with restart save a third launch on top);
+  // FOS_PLAN_CHIP_RESIDENT / FOS_PLAN_NO_CHIP_RESIDENT widen it to every served shape / switch it off.
+  {
+    const bool chip_region = p->dtype == FOS_F32 && p->n <= 8 && p->m >= 512 && p->m <= 131072 && iters >= 8;
+    if ((p->chip_mode == 1 || (p->chip_mode == 0 && chip_region)) && !p->comm && !f->precise && !f->prm.tau_from_state &&
+        f->prm.tol_grad == 0.0) {
+      const int rcc = fos_fista_run_chip(f, iters);
+      // not served, or its grid could not become co-resident within the bound (state untouched): the loops below
+      if (rcc != FOS_ERR_UNSUPPORTED && rcc != FOS_ERR_STATE) return rcc;
+    }
+  }
   if (f->prm.tol_grad > 0.0 && !p->comm) {
     // gradient-norm stop: K2 -> slab reduce (gbuf) -> norm check -> update from gbuf -> finalize, all enqueued
     for (int it = 0; it < iters; ++it) {
@@ -430,16 +444,6 @@ int fos_fista_run(fos_fista* f, int iters) {
   // Plain run: no data-dependent control (adaptive restart / stopping tolerances).  t_k and beta_k are then a fixed
   // sequence: the host passes beta_k to both kernels by value, and the scalar bookkeeping kernel runs once per call
   // instead of once per iteration (two launches per iteration instead of three).
-  // Tall-skinny plain runs: A in the LDS of up to all CUs, one grid barrier per iteration (chip_resident.hpp).  The planner's
-  // own region is where it measured at least 1.4x ahead of the two launches below (tools/bench_chip.py: 9000 ... 100000 x 5
-  // 5.6-7.6 us per iteration against 10.8-11.1); FOS_PLAN_CHIP_RESIDENT / FOS_PLAN_NO_CHIP_RESIDENT widen it to every served
-  // shape / switch it off.
-  const bool chip_region = p->dtype == FOS_F32 && p->n <= 8 && p->m >= 512 && p->m <= 131072 && iters >= 8 && !p->comm;
-  if (plain_run(f) && (p->chip_mode == 1 || (p->chip_mode == 0 && chip_region)) && !f->precise && !f->prm.tau_from_state) {
-    const int rcc = fos_fista_run_chip(f, iters);
-    // not served, or its grid could not become co-resident within the bound (state untouched): the two-launch loop below
-    if (rcc != FOS_ERR_UNSUPPORTED && rcc != FOS_ERR_STATE) return rcc;
-  }
   if (plain_run(f) && p->fused_on && !f->precise && !f->prm.tau_from_state) {      // opt-in: the one-launch persistent step
     const int rcf = fos_fista_run_fused(f, iters);
     if (rcf != FOS_ERR_UNSUPPORTED) return rcf;
@@ -594,14 +598,19 @@ int fos_fista_run_chip(fos_fista* f, int iters) {
   const int64_t cap = fos::cr_rows_cap(nc);
   if (p->dtype != FOS_F32 || p->n > 16 || p->comm || p->m < 512 || p->m > cap * (int64_t)p->ncu)
     return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_chip: fp32 A, n <= 16, 512 <= m <= rows that fit the LDS of all CUs, unsharded");
-  if (!plain_run(f) || f->precise || f->prm.tau_from_state)
-    return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_chip: plain runs only (no adaptive restart, tolerances, device-held step)");
+  // plain runs take the momentum sequence from the host; adaptive restart and the step / ratio stops are decided on the device
+  // by every workgroup alike (CTRL); the gradient-norm rule, the fp64 split gradient and a device-held step are not served
+  if (f->precise || f->prm.tau_from_state || f->prm.tol_grad > 0.0)
+    return fail(FOS_ERR_UNSUPPORTED, "fos_fista_run_chip: no gradient-norm rule, fp64 split gradient or device-held step (backtracking)");
+  const bool ctrl = !plain_run(f);
   if (iters == 0) return FOS_OK;
   int rc = flush_pending(f);
   if (rc) return rc;
   bool stopped = false;
-  if ((rc = refresh_host_scalars(f, &stopped))) return rc;
-  if (stopped) return FOS_OK;
+  if (!ctrl) {
+    if ((rc = refresh_host_scalars(f, &stopped))) return rc;
+    if (stopped) return FOS_OK;
+  }
   // about 1024 rows (four per thread) per workgroup, at most what its LDS holds: the barrier, not the pass, is the cost, and it
   // grows with the number of workgroups (tools/bench_chip.py: 100000 x 5 took 11.9 us per iteration on 256 workgroups)
   int64_t G = std::max<int64_t>(1, std::min<int64_t>(p->ncu, (p->m + 1023) / 1024));
@@ -640,7 +649,9 @@ int fos_fista_run_chip(fos_fista* f, int iters) {
   a.timeout_ticks = 100000000ull * 2ull;
   if ((rc = prof_mark(p, true))) return rc;
   const size_t lds = fos::cr_lds_bytes(nc, rpw);
-  rc = nc == 8 ? launch_chip<8>(a, (int)G, lds, p->stream) : launch_chip<16>(a, (int)G, lds, p->stream);
+  a.scal = f->scal; a.prm = f->prm;
+  if (ctrl) rc = nc == 8 ? launch_chip<8, true>(a, (int)G, lds, p->stream) : launch_chip<16, true>(a, (int)G, lds, p->stream);
+  else rc = nc == 8 ? launch_chip<8, false>(a, (int)G, lds, p->stream) : launch_chip<16, false>(a, (int)G, lds, p->stream);
   if (rc) return rc;
   if ((rc = prof_mark(p, false))) return rc;
   // A grid-wide wait that ran out (workgroups not co-resident: another kernel held CUs for longer than the bound) ends the
@@ -657,10 +668,15 @@ int fos_fista_run_chip(fos_fista* f, int iters) {
   }
   f->pending = false;
   f->y_valid = false;                              // the fp32 y vector of the two-launch path is not maintained here
+  f->plain_count = 0;
+  if (ctrl) {                                      // the kernel advanced FistaScalars itself; the host's mirrors are stale
+    f->host_valid = false;
+    f->h_k = k_before; f->h_t = t_before; f->h_beta = beta_before;
+    return FOS_OK;
+  }
   hipLaunchKernelGGL(fos::fista_finalize_plain_kernel, dim3(1), dim3(64), 0, p->stream, stats, iters >= 2 ? stats + 4 : (const double*)nullptr,
                      1, stats + 8, 1, f->scal, f->h_t, f->h_beta, f->h_k);
   LAUNCH_CHECK();
-  f->plain_count = 0;
   return FOS_OK;
 }
 

@@ -43,7 +43,7 @@ enum { FOS_PLAN_NO_RESIDENT = 1, FOS_PLAN_NO_TALL = 2, FOS_PLAN_NO_WIDE = 4, FOS
        FOS_PLAN_FUSED_MFMA = 256,   /* OPT IN: plain fos_fista_run calls take the one-launch persistent step of
                                        fos_fista_run_fused (LDS-staged panels, row dots on the matrix cores, resident
                                        iterate) wherever the shape is served */
-       FOS_PLAN_CHIP_RESIDENT = 512, /* plain fos_fista_run calls on tall-skinny problems (n <= 16) take fos_fista_run_chip
+       FOS_PLAN_CHIP_RESIDENT = 512, /* fos_fista_run calls without backtracking on tall-skinny problems (n <= 16) take fos_fista_run_chip
                                        (A resident in the LDS of up to all CUs, one grid barrier per iteration) WHEREVER
                                        it is served ...                                                              */
        FOS_PLAN_NO_CHIP_RESIDENT = 1024 /* ... or never; neither bit: the planner takes it where it measured at least 1.4x
@@ -285,11 +285,14 @@ int fos_fista_run_multi(fos_fista* const* fs, int nv, int iters);
  * otherwise).  Synchronises at the end (reports a timed-out grid-wide wait as FOS_ERR_STATE).  The default two-launch step
  * measures faster: this entry point exists so that the comparison is a measurement. */
 int fos_fista_run_fused(fos_fista* f, int iters);
-/* Tall-skinny problems beyond one CU's LDS, OPT-IN (csrc/chip_resident.hpp): `iters` plain iterations (no adaptive restart,
- * tolerances or backtracking: FOS_ERR_UNSUPPORTED otherwise) in ONE launch with A resident in the LDS of up to all CUs and one
- * grid-wide barrier per iteration - every workgroup reads all partial gradients (n <= 16) and applies the identical fp64 update
- * to its copy of the iterate.  fp32 A, n <= 16, 512 <= m <= (150 KiB / row bytes) x #CUs, unsharded.  Same state hand-over as
- * fos_fista_run (the two can be mixed).  Synchronises at the end (it reports a timed-out barrier). */
+/* Tall-skinny problems beyond one CU's LDS (csrc/chip_resident.hpp): `iters` iterations in ONE launch with A resident in the
+ * LDS of up to all CUs and one grid-wide barrier per iteration - every workgroup reads all partial gradients (n <= 16) and
+ * applies the identical fp64 update to its copy of the iterate; adaptive restart and the step / ratio stops are decided the
+ * same way, by every workgroup alike.  Not served (FOS_ERR_UNSUPPORTED): the gradient-norm rule, backtracking, the fp64 split
+ * gradient, sharded problems.  fp32 A, n <= 16, 512 <= m <= (150 KiB / row bytes) x #CUs.  Same state hand-over as
+ * fos_fista_run, which takes this loop by itself in the planner's region (FOS_PLAN_CHIP_RESIDENT above).  Every grid-wide
+ * wait is bounded (2 s); one that runs out ends the launch before anything is written back: FOS_ERR_STATE, the handle is as
+ * before the call.  Synchronises at the end. */
 int fos_fista_run_chip(fos_fista* f, int iters);
 /* Measurement hook of the persistent step: stamps = device buffer of #CUs x 8 uint64 (NULL = off); every workgroup then
  * records the 100 MHz wall clock of the LAST iteration of a fos_fista_run_fused call - [0] phase A starts, [1] phase A

@@ -1670,8 +1670,9 @@ def test_chip_resident_plain_loop(fos, m, n):
     """Opt-in (fos_fista_run_chip): tall-skinny plain runs with A resident in the LDS of up to all CUs and ONE grid barrier
     per iteration - every workgroup reads all partial gradients and updates its own copy of the iterate.  Against the oracle
     (1e-5) and the default two-launch loop (1e-6) for FISTA (lasso; l2 in the smooth
-    part), FISTA-delta and fused ISTA with the elastic-net prox; the state carries over between chip calls and between the
-    two forms, step norms included; ill-conditioned columns (the reference's unstandardised features); unsupported runs refuse."""
+    part), FISTA-delta and fused ISTA with the elastic-net prox; adaptive restart and the ratio stop decided on the device; the
+    state carries over between chip calls and between the two forms, step norms included; ill-conditioned columns (the
+    reference's unstandardised features); unsupported runs refuse or fall through."""
     from fastoptsolver_amd import _core
     rng = np.random.default_rng(m + n)
     A = rng.standard_normal((m, n)).astype(np.float32)
@@ -1708,8 +1709,28 @@ def test_chip_resident_plain_loop(fos, m, n):
         if c["mode"] == _core._lib.MODE_FISTA:
             x_o = orc.fista(A64, b64, "elasticnet" if c["a2"] else "lasso", c["a1"], c["a2"], max_iter=40, L=L)
             assert _data.rel(xc, x_o) < TOL, c
-    st = _core.Fista(prob); st.reset(1.0 / L, 0.05 * lam, 0.0, adaptive_restart=True)
-    assert not st.run_chip(3)                                          # data-dependent control: not served
+    st = _core.Fista(prob); st.reset(1.0 / L, 0.05 * lam, 0.0, tol_grad=1e-3)
+    assert not st.run_chip(3)                                          # the gradient-norm rule is not served
+    # data-dependent control - adaptive restart, ratio stop - decided on the device by every workgroup alike: same iterate,
+    # same restarts / stopping iteration as the two-launch loop with its one-wave bookkeeping kernel
+    # (on STANDARDISED columns, where 40 iterations are still moving: with the x300 column above the loop is at its fixed point
+    #  after two steps, the two-launch loop's step norms are then the rounding noise of its fp32 y against exact zeros here,
+    #  and restart decisions on noise are not comparable)
+    As = rng.standard_normal((m, n)).astype(np.float32)
+    As[:, 1] += 0.9 * As[:, 0]
+    probs = fos.prepare(torch.as_tensor(As).cuda(), b)
+    probs.replan(no_resident=True, chip_resident=False)
+    Ls = float(np.linalg.norm(As.astype(np.float64), 2) ** 2)
+    lams = float(np.max(np.abs(As.astype(np.float64).T @ b64)))
+    for ckw in (dict(adaptive_restart=True), dict(adaptive_restart=True, restart_threshold=0.9, tol_ratio=0.5), dict(tol_ratio=0.9)):
+        ref = _core.Fista(probs); ref.reset(1.0 / Ls, 1e-3 * lams, 0.0, **ckw); ref.run(40)
+        ch = _core.Fista(probs); ch.reset(1.0 / Ls, 1e-3 * lams, 0.0, **ckw)
+        assert ch.run_chip(15) and ch.run_chip(10)
+        ch.run(5)
+        assert ch.run_chip(10)
+        sr, sc = ref.status(), ch.status()
+        assert (int(sc.k), int(sc.stopped), int(sc.restarts)) == (int(sr.k), int(sr.stopped), int(sr.restarts)), ckw
+        assert _data.rel(ch.x_tensor().cpu().numpy(), ref.x_tensor().cpu().numpy()) < 1e-6, ckw
     # The Python boundary's plain calls take it by the planner's choice (n <= 8, up to 131072 rows) or by the plan flag
     # (FOS_PLAN_CHIP_RESIDENT: wherever served); flagged runs fall through to the two-launch loop.  Kernel timing tells
     # which loop ran: the chip loop is ONE profiled launch per call, the two-launch loop one per iteration.
@@ -1726,5 +1747,8 @@ def test_chip_resident_plain_loop(fos, m, n):
         assert (launches <= 2) == expect_chip, (force, launches)
     prob2 = fos.prepare(torch.as_tensor(A).cuda(), b)
     prob2.replan(no_resident=True, chip_resident=True)
-    x2 = fos.fista(prob2, None, "lasso", 0.05 * lam, 0.0, max_iter=60, L=L, adaptive_restart=True)
-    assert _data.rel(_np(x2), orc.fista(A64, b64, "lasso", 0.05 * lam, 0.0, max_iter=60, L=L, adaptive_restart=True)) < TOL
+    for fkw in (dict(adaptive_restart=True), dict(adaptive_restart=True, tol_ratio=0.7), dict(tol=1e-9 * lam), dict(backtracking=True)):
+        x2 = fos.fista(prob2, None, "lasso", 0.05 * lam, 0.0, max_iter=60, L=L, **fkw)
+        x_o2, met = orc.fista(A64, b64, "lasso", 0.05 * lam, 0.0, max_iter=60, L=L, return_metrics=True, **fkw)
+        assert _data.rel(_np(x2), x_o2) < TOL, fkw
+        assert fos.get_metrics()["grad_num_calls"] == met["grad_num_calls"], fkw
