@@ -411,7 +411,10 @@ int fos_fista_run(fos_fista* f, int iters) {
   // 9000 ... 100000 x 5 5.6-7.7 us per iteration against 10.8-11.2; runs with restart save a third launch on top);
   // FOS_PLAN_CHIP_RESIDENT / FOS_PLAN_NO_CHIP_RESIDENT widen it to every served shape / switch it off.
   {
-    const bool chip_region = p->dtype == FOS_F32 && p->n <= 8 && p->m >= 512 && p->m <= 131072 && iters >= 8;
+    // (9..16 columns - the 16-column instantiation carries twice the registers: 20000 x 16 1.2x plain, 1.6x with restart, even at
+    //  100000 x 16)
+    const bool chip_region = p->dtype == FOS_F32 && p->m >= 512 && iters >= 8 &&
+                             (p->n <= 8 ? p->m <= 131072 : (p->n <= 16 && p->m <= 32768));
     if ((p->chip_mode == 1 || (p->chip_mode == 0 && chip_region)) && !p->comm && !f->precise && !f->prm.tau_from_state &&
         f->prm.tol_grad == 0.0) {
       const int rcc = fos_fista_run_chip(f, iters);

@@ -47,7 +47,7 @@ enum { FOS_PLAN_NO_RESIDENT = 1, FOS_PLAN_NO_TALL = 2, FOS_PLAN_NO_WIDE = 4, FOS
                                        (A resident in the LDS of up to all CUs, one grid barrier per iteration) WHEREVER
                                        it is served ...                                                              */
        FOS_PLAN_NO_CHIP_RESIDENT = 1024 /* ... or never; neither bit: the planner takes it where it measured at least 1.4x
-                                       ahead - fp32, n <= 8, 512 <= m <= 131072 rows, calls of 8 iterations or more.
+                                       ahead - fp32, 512 <= m <= 131072 rows at n <= 8 (32768 rows at n <= 16), calls of 8 iterations or more.
                                        Problems that fit ONE CU's LDS keep the single-workgroup resident loop. */ };
 
 typedef struct fos_problem fos_problem;   /* A, b, launch plan, workspace            */

@@ -1735,7 +1735,8 @@ def test_chip_resident_plain_loop(fos, m, n):
     # (FOS_PLAN_CHIP_RESIDENT: wherever served); flagged runs fall through to the two-launch loop.  Kernel timing tells
     # which loop ran: the chip loop is ONE profiled launch per call, the two-launch loop one per iteration.
     x_o = orc.fista(A64, b64, "lasso", 0.05 * lam, 0.0, max_iter=60, L=L)
-    for force, expect_chip in ((None, n <= 8 and 512 <= m <= 131072), (True, m >= 512), (False, False)):
+    in_region = m >= 512 and (m <= 131072 if n <= 8 else m <= 32768)
+    for force, expect_chip in ((None, in_region), (True, m >= 512), (False, False)):
         prob2 = fos.prepare(torch.as_tensor(A).cuda(), b)
         prob2.replan(no_resident=True, chip_resident=force)
         assert prob2.plan()["chip_resident"] == (1 if force else 0)
