@@ -512,7 +512,7 @@ def roofline_obj(res, traffic_key):
         # context, not the denominator of `frac`: a read-only pass over the same A on this box, this run
         "stream_read_measured": {"gbps": res["read_gbps"], "us_per_pass_over_A": res["read_us"],
                                  "kernel_over_stream_read": (res["achieved_gbps"] or 0.0) / res["read_gbps"],
-                                 "what": "fos_stream_read_probe: loads + adds only, same buffer, HIP events; the faster of two access orders (a contiguous range per workgroup / one window swept by all)"},
+                                 "what": "fos_stream_read_probe: loads + adds only, same buffer, HIP events; the fastest of three access orders (a contiguous range per workgroup / one window swept by all in 8 KiB / in 64 KiB pieces)"},
     }
 
 

@@ -847,11 +847,25 @@ int launch_cluster_pass(fos_problem* p) {
 // profiles/r03_read_probe_sweep.txt: 7.19 TB/s; grid-stride order 7.1, temporal loads 6.2, 4 workgroups per CU 6.1): one
 // 512-thread workgroup per CU streams its own contiguous range with 8 independent 16-byte non-temporal loads in flight per
 // thread - the access pattern of the single-pass kernel without its arithmetic.
-template <bool BLOCKS>
+// ORDER 0: every workgroup streams its own contiguous range; 1: all workgroups sweep one window, 8 KiB per workgroup and trip;
+// 2: the same with 64 KiB per workgroup and trip - the interleaved row order of the product kernel at 64 KiB rows
+template <int ORDER>
 __global__ __launch_bounds__(512) void stream_read_kernel(const fos::f32x4* __restrict__ src, size_t n16, float* __restrict__ sink) {
   constexpr int UNR = 8, THREADS = 512;
+  constexpr bool BLOCKS = ORDER == 0;
   fos::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (BLOCKS) {                               // every workgroup streams its own contiguous range
+  if constexpr (ORDER == 2) {
+    constexpr size_t CH = (size_t)UNR * THREADS;       // 16-byte units per workgroup and trip = 64 KiB
+    size_t base = (size_t)blockIdx.x * CH;
+    for (; base + CH <= n16; base += (size_t)gridDim.x * CH) {
+      fos::f32x4 v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) v[u] = __builtin_nontemporal_load(src + base + threadIdx.x + (size_t)u * THREADS);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) acc += v[u];
+    }
+    for (size_t i = base + threadIdx.x; i < n16 && i < base + CH; i += THREADS) acc += __builtin_nontemporal_load(src + i);
+  } else if constexpr (BLOCKS) {                        // every workgroup streams its own contiguous range
     const size_t per = ((n16 + gridDim.x - 1) / gridDim.x + THREADS * UNR - 1) / (THREADS * UNR) * (THREADS * UNR);
     const size_t lo = per * blockIdx.x, hi = lo + per < n16 ? lo + per : n16;
     size_t i = lo + threadIdx.x;
@@ -1015,11 +1029,13 @@ int fos_stream_read_probe(const void* buf, size_t bytes, int launches, void* str
   hipEvent_t e0 = nullptr, e1 = nullptr;
   hipError_t e = hipEventCreate(&e0);
   if (e == hipSuccess) e = hipEventCreate(&e1);
-  // both orders - contiguous ranges per workgroup, one window swept by all - and the faster one counts: which of the two
-  // leads depends on the size and on the state of the device (profiles/r03_row_order.md), as for the product kernel
+  // three orders - contiguous ranges per workgroup, one window swept by all in 8 KiB or in 64 KiB pieces - and the fastest one
+  // counts: which of them leads depends on the size and on the state of the device (profiles/r03_row_order.md), as for the
+  // product kernel
   float ms = 0.f;
-  for (int order = 0; order < 2 && e == hipSuccess; ++order) {
-    void (*kern)(const fos::f32x4*, size_t, float*) = order == 0 ? stream_read_kernel<true> : stream_read_kernel<false>;
+  for (int order = 0; order < 3 && e == hipSuccess; ++order) {
+    void (*kern)(const fos::f32x4*, size_t, float*) =
+        order == 0 ? stream_read_kernel<0> : order == 1 ? stream_read_kernel<1> : stream_read_kernel<2>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, st, (const fos::f32x4*)buf, n16, sink);      // warm-up
     e = hipEventRecord(e0, st);
     for (int i = 0; i < launches && e == hipSuccess; ++i) {
